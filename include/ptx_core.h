@@ -1,0 +1,332 @@
+/* ptx_core.h — C ABI of the MI355X render core (libmi355_pt.so).
+ *
+ * This is the one boundary between a host renderer (the reference's Rust host:
+ * scene loading, SAH build + collapse, camera, tonemapping, OIDN) and the
+ * hand-written gfx950 HIP kernels.  It sits where the reference's
+ * `RenderLoop::render_pass` sits (src/raytracer/renderloop/mod.rs:9-22) and
+ * where `run_benchmark`'s `for sample` loop sits (src/main.rs:123-141).
+ *
+ * Conventions
+ *   - every call returns int32 status, 0 == PTX_OK; nothing throws or aborts
+ *     across the boundary; `ptx_last_error` gives a message;
+ *   - the caller owns every host buffer it passes in; the library owns all
+ *     device memory (except explicit `*_dev` outputs, which are caller-owned
+ *     device pointers);
+ *   - matrices are column-major float[16], exactly glam's `Mat4::to_cols_array`;
+ *   - one context drives one GPU; it is not re-entrant (the reference's render
+ *     loop is single-caller too).
+ *
+ * All struct layouts below are plain `repr(C)`-compatible PODs so that a Rust
+ * `-sys` crate, cgo or ctypes can bind them directly.
+ */
+#ifndef PTX_CORE_H
+#define PTX_CORE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTX_ABI_VERSION 1
+
+enum {
+    PTX_OK = 0,
+    PTX_ERR_INVALID = 1,      /* bad argument / scene fails validation          */
+    PTX_ERR_NO_DEVICE = 2,    /* no HIP device / device index out of range      */
+    PTX_ERR_HIP = 3,          /* a HIP runtime call failed                      */
+    PTX_ERR_NO_SCENE = 4,     /* render/trace before ptx_upload_scene           */
+    PTX_ERR_STACK_OVERFLOW = 5, /* a traversal needed > 64 stack entries on one
+                                   BVH level: the reference would panic on its
+                                   bounds check (accel/bvh.rs:320,361,379,408)  */
+    PTX_ERR_UNSUPPORTED = 6
+};
+
+/* ---- acceleration structure, as the reference host builds it ------------- */
+
+/* Bit-for-bit the reference's `Bvh8Node` (accel/bvh.rs:86-98):
+ * #[repr(C, align(64))], 232 B payload, sizeof 256.  Child word
+ * (accel/bvh.rs:116-169): internal = node index (bit31 = 0); leaf =
+ * 1<<31 | (count-1)<<24 | prim_start. */
+typedef struct __attribute__((aligned(64))) PtxBvh8Node {
+    float min_x[8], max_x[8];
+    float min_y[8], max_y[8];
+    float min_z[8], max_z[8];
+    uint32_t children[8];
+    uint8_t valid_mask;
+    uint8_t _padding[7];
+} PtxBvh8Node;
+
+/* `Bvh8` (accel/bvh.rs:266-269). */
+typedef struct PtxBvh8 {
+    const PtxBvh8Node* nodes;
+    uint32_t n_nodes;
+    const uint32_t* primitive_indices;
+    uint32_t n_primitive_indices;
+} PtxBvh8;
+
+/* One `Blas<TriangleMesh>` holding exactly one `TriangleMesh`
+ * (shape/triangle_mesh.rs:6-14; the loader never builds anything else:
+ * loader/gltf.rs:300-302).  `bounds_*` is the mesh's unpadded position bounds
+ * (triangle_mesh.rs:56-61) == slot 0 of the one-node item BVH of the Blas
+ * (accel/mod.rs:27-52). */
+typedef struct PtxMesh {
+    const float* positions;  uint32_t n_positions;   /* xyz triples            */
+    const float* normals;    uint32_t n_normals;     /* xyz triples, 0 = none  */
+    const float* uvs;        uint32_t n_uvs;         /* uv pairs,   0 = none   */
+    const uint32_t* indices; uint32_t n_triangles;   /* [u32;3] per triangle   */
+    uint32_t material_id;
+    PtxBvh8 bvh;                                     /* over triangles, leaf 4 */
+    float bounds_min[3];
+    float bounds_max[3];
+} PtxMesh;
+
+/* `Instance` (accel/mod.rs:75-81). */
+typedef struct PtxInstance {
+    uint32_t blas_index;
+    float transform[16];
+    float inverse_transform[16];
+    float normal_matrix[16];       /* (M^-1)^T */
+} PtxInstance;
+
+/* ---- shading inputs -------------------------------------------------------- */
+
+/* `Material` (material.rs:12-36); texture ids are -1 for None.  Only the
+ * fields the integrator reads are carried. */
+typedef struct PtxMaterial {
+    int32_t base_color_texture;
+    int32_t metallic_roughness_texture;
+    int32_t normal_texture;
+    int32_t emissive_texture;
+    float base_color_factor[4];
+    float roughness_factor;
+    float metallic_factor;
+    float normal_scale;
+    float emissive_factor[3];
+    float ior;
+    float transmission;
+    float subsurface;
+    float subsurface_radius[3];
+    float subsurface_albedo[3];
+    float subsurface_anisotropy;
+    float subsurface_entry_tint[3];
+    float subsurface_exit_tint[3];
+} PtxMaterial;
+
+/* `Texture` (texture.rs:4-12): f32 RGB texels, row-major, or a solid colour
+ * (`texels == NULL`). */
+typedef struct PtxTexture {
+    uint32_t width, height;
+    const float* texels;           /* width*height*3, NULL => SolidColor(solid) */
+    float solid[3];
+} PtxTexture;
+
+/* `TextureSky` (sky/texture.rs:6-14) incl. the host-built CDFs (:67-112). */
+typedef struct PtxSky {
+    PtxTexture texture;
+    const float* marginal_cdf;      /* height + 1                      */
+    const float* conditional_cdfs;  /* height * (width + 1), row-major */
+    uint32_t width, height;         /* (1,1) for a solid colour        */
+    float total_weight;
+    float rotation;
+} PtxSky;
+
+/* `Option<DirectionalLight>` (light.rs:4-10). */
+typedef struct PtxSun {
+    uint32_t enabled;
+    float direction[3];
+    float color[3];
+    float cos_angle;
+    float pdf;
+} PtxSun;
+
+/* `BlueNoiseTexture` (bluenoise.rs:3-6): size*size Vec2 samples. */
+typedef struct PtxBlueNoise {
+    uint32_t size;
+    const float* samples;
+} PtxBlueNoise;
+
+/* What `Scene::new` holds after `Tlas::build` (scene.rs:22-40,
+ * accel/mod.rs:166-192) plus the render loop's two blue-noise tables
+ * (renderloop/parallel.rs:19-28). */
+typedef struct PtxSceneDesc {
+    uint32_t abi_version;
+    const PtxMesh* meshes;          uint32_t n_meshes;      /* == blases */
+    const PtxInstance* instances;   uint32_t n_instances;
+    PtxBvh8 tlas;                                           /* over instances, leaf 1 */
+    const PtxMaterial* materials;   uint32_t n_materials;
+    const PtxTexture* textures;     uint32_t n_textures;
+    PtxSky sky;
+    PtxSun sun;
+    PtxBlueNoise blue_noise_pixel;  /* seed 12345 */
+    PtxBlueNoise blue_noise_lens;   /* seed 67890 */
+} PtxSceneDesc;
+
+/* The part of `Camera` that `generate_ray_dof` reads (camera.rs:66-95). */
+typedef struct PtxCamera {
+    float inv_vp_matrix[16];
+    float aperture;
+    float focus_distance;
+    float right[3];                /* Camera::right()                  */
+    float up[3];                   /* right.cross(forward)             */
+} PtxCamera;
+
+/* ---- ray batches (parity/debug entry) ------------------------ */
+
+/* `Ray` as the caller builds it: `Ray::new(origin, direction)` gives
+ * t_min = 0.001, t_max = +inf; `with_t_max` overrides t_max (ray.rs:12-27).
+ * inv_direction is recomputed by the library exactly as Ray::new does. */
+typedef struct PtxRay {
+    float origin[3];
+    float direction[3];
+    float t_max;
+} PtxRay;
+
+#define PTX_MISS 0xFFFFFFFFu
+
+/* What the reference's closures know and `HitData` drops (ray.rs:29-37):
+ * the TLAS primitive index (instance), the mesh primitive index (triangle),
+ * world t, and the barycentrics of `intersect_triangle`. */
+typedef struct PtxHitRecord {
+    uint32_t inst_idx;             /* PTX_MISS when nothing was hit    */
+    uint32_t tri_idx;
+    float t;
+    float u, v;
+} PtxHitRecord;
+
+enum { PTX_TRACE_CLOSEST = 0, PTX_TRACE_ANY = 1 };
+
+/* Event counts that define the algorithmic bytes of SURVEY.md §8(d). */
+typedef struct PtxCounters {
+    uint64_t rays_closest;          /* Scene::hit calls                           */
+    uint64_t rays_any;              /* Scene::hit_any calls                       */
+    uint64_t node_visits;           /* every pop that reaches node.intersect      */
+    uint64_t node_children;         /* sum of popcount(valid_mask) over visits    */
+    uint64_t prim_index_reads;
+    uint64_t triangle_tests;
+    uint64_t instance_entries;
+    uint64_t instance_hits;         /* Instance::hit returned Some                */
+    uint64_t hitdata_built;         /* compute_hit_data for a path vertex         */
+    uint64_t material_fetches;
+    uint64_t texture_lookups;
+    uint64_t cdf_probes;
+    uint64_t sky_pdf_evals;
+    uint64_t sky_texel_lookups;
+    uint64_t primary_rays;
+    uint64_t pixel_samples_written;
+    uint64_t sss_steps;
+} PtxCounters;
+
+/* `AdaptiveSamplingConfig` (renderloop/parallel.rs:13-17). */
+typedef struct PtxAdaptiveConfig {
+    uint32_t min_samples;
+    float variance_threshold;
+    uint64_t max_samples_per_pass;
+} PtxAdaptiveConfig;
+
+/* Per-kernel-class device time of the calls since the last reset (HIP events
+ * on the library's own stream; only recorded while profiling is enabled). */
+typedef struct PtxTimings {
+    double raygen_ms, extend_ms, shade_ms, shadow_ms, accumulate_ms, other_ms;
+    uint64_t extend_launches, shade_launches, shadow_launches;
+} PtxTimings;
+
+typedef struct PtxContext PtxContext;
+
+/* ---- lifecycle ------------------------------------------------------------- */
+int32_t ptx_create(int32_t device_index, PtxContext** out_ctx);
+int32_t ptx_destroy(PtxContext* ctx);
+const char* ptx_last_error(const PtxContext* ctx);   /* ctx may be NULL */
+
+/* Mirrors the result of `Scene::new` (scene.rs:22-40): copies and repacks the
+ * whole scene into HBM.  The descriptor may be freed afterwards. */
+int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* scene);
+/* Mirrors `Camera` after `update_matrix` (camera.rs:51-60). */
+int32_t ptx_set_camera(PtxContext* ctx, const PtxCamera* camera);
+
+/* Pixel-tile partition for multi-GPU frames: this context renders only 8x8
+ * tiles with tile_index % world == rank.  Default (0, 1) = everything. */
+int32_t ptx_set_partition(PtxContext* ctx, uint32_t rank, uint32_t world);
+
+/* ---- the reference's render-loop entry points ------------------------------ */
+
+/* `RenderLoop::render_pass` (renderloop/parallel.rs:171-194): one sample per
+ * pixel with `PathTracer<max_bounces>`; out_rgb = width*height*3 floats
+ * (row-major Vec<Vec3>). */
+int32_t ptx_render_pass(PtxContext* ctx, uint32_t width, uint32_t height,
+                        uint32_t sample_index, uint32_t max_bounces, float* out_rgb);
+
+/* `render_first_pass_with_aov` (renderloop/parallel.rs:125-168): sample 0 plus
+ * first-hit albedo / normal*0.5+0.5. */
+int32_t ptx_render_first_pass_aov(PtxContext* ctx, uint32_t width, uint32_t height,
+                                  uint32_t max_bounces, float* out_rgb,
+                                  float* out_albedo, float* out_normal);
+
+/* `render_pixels` (renderloop/parallel.rs:58-78): work list of (x, y,
+ * sample_index) triplets; out_rgb = n*3 floats in list order. */
+int32_t ptx_render_pixels(PtxContext* ctx, uint32_t width, uint32_t height,
+                          const uint32_t* xys, uint64_t n, uint32_t max_bounces,
+                          float* out_rgb);
+
+/* `UnshadedRenderer` through `render_pass` (renderer/unshaded.rs:7-23,
+ * app.rs:178-193): the interactive low-res preview. */
+int32_t ptx_render_pass_unshaded(PtxContext* ctx, uint32_t width, uint32_t height,
+                                 uint32_t sample_index, float* out_rgb);
+
+/* ---- device-resident framebuffer: the `for sample` loop on the GPU --------- */
+
+/* `Framebuffer::new` / `AdaptiveFramebuffer::new` + `reset`
+ * (framebuffer.rs:17-42, 84-108).  adaptive != 0 keeps sum, sum_sq, counts. */
+int32_t ptx_fb_reset(PtxContext* ctx, uint32_t width, uint32_t height, int32_t adaptive);
+
+/* `for sample in first..first+count { render_pass; accumulate }`
+ * (main.rs:124-133, framebuffer.rs:44-50, 118-125).  Nothing leaves the GPU. */
+int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t count,
+                             uint32_t max_bounces);
+
+/* `render_adaptive_pass` (renderloop/parallel.rs:80-123) incl.
+ * `get_noisy_pixels` (framebuffer.rs:181-214); returns the work-list length. */
+int32_t ptx_fb_adaptive_pass(PtxContext* ctx, const PtxAdaptiveConfig* cfg,
+                             uint32_t max_bounces, uint64_t* out_rendered);
+
+/* `min_sample_count` / `max_sample_count` / `total_samples`
+ * (framebuffer.rs:132-142) over the pixels this context owns. */
+int32_t ptx_fb_stats(PtxContext* ctx, uint32_t* out_min, uint32_t* out_max,
+                     uint64_t* out_total);
+
+/* Raw accumulators to host (any pointer may be NULL): sum / sum_sq are
+ * width*height*3 floats, counts width*height u32. */
+int32_t ptx_fb_read(PtxContext* ctx, float* out_sum, float* out_sum_sq, uint32_t* out_counts);
+/* `to_color_buffer` / `get_averaged` (framebuffer.rs:52-59, 216-228). */
+int32_t ptx_fb_read_mean(PtxContext* ctx, float* out_mean);
+/* Same accumulators into caller-owned DEVICE memory (e.g. a torch tensor that
+ * an RCCL all-gather then combines across GPUs).  Not synchronised: ordered
+ * on the library stream; call ptx_sync before another stream reads it. */
+int32_t ptx_fb_export_dev(PtxContext* ctx, float* d_sum, float* d_sum_sq, uint32_t* d_counts);
+int32_t ptx_sync(PtxContext* ctx);
+
+/* ---- parity / measurement --------------------------------------------------- */
+
+/* `Scene::hit` / `Scene::hit_any` (scene.rs:44-50) on a caller's ray batch.
+ * mode CLOSEST fills out_hits[n]; mode ANY fills out_any[n] (0/1). */
+int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t mode,
+                        PtxHitRecord* out_hits, uint8_t* out_any);
+
+/* The primary rays `render_pixel` would generate (renderloop/parallel.rs:31-56,
+ * bluenoise.rs:156-172, camera.rs:66-95), for the RNG-seed parity check. */
+int32_t ptx_generate_primary_rays(PtxContext* ctx, uint32_t width, uint32_t height,
+                                  uint32_t sample_index, PtxRay* out_rays);
+
+int32_t ptx_set_counting(PtxContext* ctx, int32_t enabled);   /* counted kernels are slower */
+int32_t ptx_reset_counters(PtxContext* ctx);
+int32_t ptx_get_counters(PtxContext* ctx, PtxCounters* out);
+
+int32_t ptx_set_profiling(PtxContext* ctx, int32_t enabled);
+int32_t ptx_reset_timings(PtxContext* ctx);
+int32_t ptx_get_timings(PtxContext* ctx, PtxTimings* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTX_CORE_H */

@@ -1,0 +1,291 @@
+"""Render-loop mirror over the HIP render core (ctypes over libmi355_pt.so).
+
+`HipRenderLoop` has the shape of the reference's `RenderLoop` trait
+(renderloop/mod.rs:9-22) and of `ParallelRenderLoop`'s inherent methods
+(renderloop/parallel.rs:58-168): same names, same argument meaning, same
+results layout (row-major Vec<Vec3> -> (H, W, 3) float32).  There is no CPU
+fallback: if the HIP library or a GPU is missing every call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi as abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEVICE_LIB_PATH = os.path.join(_HERE, "lib", "libmi355_pt.so")
+
+EXPORTS = [
+    "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_upload_scene", "ptx_set_camera", "ptx_set_partition",
+    "ptx_render_pass", "ptx_render_first_pass_aov", "ptx_render_pixels", "ptx_render_pass_unshaded",
+    "ptx_fb_reset", "ptx_fb_render_passes", "ptx_fb_adaptive_pass", "ptx_fb_stats", "ptx_fb_read",
+    "ptx_fb_read_mean", "ptx_fb_export_dev", "ptx_sync", "ptx_trace_batch", "ptx_generate_primary_rays",
+    "ptx_set_counting", "ptx_reset_counters", "ptx_get_counters", "ptx_set_profiling", "ptx_reset_timings",
+    "ptx_get_timings",
+]
+
+
+class RenderCoreError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libmi355_pt.so (no GPU needed to load it; needed for ptx_create)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(DEVICE_LIB_PATH):
+        raise RenderCoreError(f"{DEVICE_LIB_PATH} is missing — build it with __graft_entry__.build(); "
+                              "there is no CPU fallback for the render core")
+    L = C.CDLL(DEVICE_LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    L.ptx_create.argtypes = [i32, C.POINTER(vp)]
+    L.ptx_destroy.argtypes = [vp]
+    L.ptx_last_error.argtypes = [vp]
+    L.ptx_last_error.restype = C.c_char_p
+    L.ptx_upload_scene.argtypes = [vp, C.POINTER(abi.PtxSceneDesc)]
+    L.ptx_set_camera.argtypes = [vp, C.POINTER(abi.PtxCamera)]
+    L.ptx_set_partition.argtypes = [vp, u32, u32]
+    L.ptx_render_pass.argtypes = [vp, u32, u32, u32, u32, vp]
+    L.ptx_render_first_pass_aov.argtypes = [vp, u32, u32, u32, vp, vp, vp]
+    L.ptx_render_pixels.argtypes = [vp, u32, u32, vp, u64, u32, vp]
+    L.ptx_render_pass_unshaded.argtypes = [vp, u32, u32, u32, vp]
+    L.ptx_fb_reset.argtypes = [vp, u32, u32, i32]
+    L.ptx_fb_render_passes.argtypes = [vp, u32, u32, u32]
+    L.ptx_fb_adaptive_pass.argtypes = [vp, C.POINTER(abi.PtxAdaptiveConfig), u32, C.POINTER(u64)]
+    L.ptx_fb_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
+    L.ptx_fb_read.argtypes = [vp, vp, vp, vp]
+    L.ptx_fb_read_mean.argtypes = [vp, vp]
+    L.ptx_fb_export_dev.argtypes = [vp, vp, vp, vp]
+    L.ptx_sync.argtypes = [vp]
+    L.ptx_trace_batch.argtypes = [vp, vp, u64, i32, vp, vp]
+    L.ptx_generate_primary_rays.argtypes = [vp, u32, u32, u32, vp]
+    L.ptx_set_counting.argtypes = [vp, i32]
+    L.ptx_reset_counters.argtypes = [vp]
+    L.ptx_get_counters.argtypes = [vp, C.POINTER(abi.PtxCounters)]
+    L.ptx_set_profiling.argtypes = [vp, i32]
+    L.ptx_reset_timings.argtypes = [vp]
+    L.ptx_get_timings.argtypes = [vp, C.POINTER(abi.PtxTimings)]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name != "ptx_last_error":
+            fn.restype = i32
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class PathTracer:
+    """`PathTracer<const MAX_BOUNCES: u32>` (renderer/pathtracer.rs:16): 8 in --benchmark, 16 in the app."""
+
+    def __init__(self, max_bounces=8):
+        self.max_bounces = int(max_bounces)
+
+
+class UnshadedRenderer:
+    """`UnshadedRenderer` (renderer/unshaded.rs:5): the moving-camera preview."""
+
+
+class AdaptiveSamplingConfig:
+    """`AdaptiveSamplingConfig` (renderloop/parallel.rs:13-17); app defaults: app.rs:139-143."""
+
+    def __init__(self, min_samples=64, variance_threshold=0.001, max_samples_per_pass=None):
+        self.min_samples = int(min_samples)
+        self.variance_threshold = float(variance_threshold)
+        self.max_samples_per_pass = max_samples_per_pass
+
+
+class HipRenderLoop:
+    """The render core behind the reference's `RenderLoop` interface.
+
+    The reference borrows `&scene` / `&camera` on every call; here the scene
+    is uploaded to HBM the first time it is seen (`Scene::new` happens once in
+    the reference too) and the camera (80 bytes) is sent with every call.
+    """
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        st = self.L.ptx_create(int(device), C.byref(h))
+        if st != abi.PTX_OK:
+            msg = self.L.ptx_last_error(None)
+            raise RenderCoreError(f"ptx_create failed: {abi.ERROR_NAMES.get(st, st)}: {msg.decode() if msg else ''}")
+        self._h = h
+        self._scene = None
+
+    # -- plumbing ---------------------------------------------------------------
+    def _check(self, st, what):
+        if st != abi.PTX_OK:
+            msg = self.L.ptx_last_error(self._h)
+            raise RenderCoreError(f"{what}: {abi.ERROR_NAMES.get(st, st)}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.ptx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _bind(self, scene, camera):
+        if scene is not self._scene:
+            self._check(self.L.ptx_upload_scene(self._h, scene.desc), "ptx_upload_scene")
+            self._scene = scene
+        if camera is not None:
+            self._check(self.L.ptx_set_camera(self._h, C.byref(camera)), "ptx_set_camera")
+
+    def set_partition(self, rank, world):
+        self._check(self.L.ptx_set_partition(self._h, rank, world), "ptx_set_partition")
+
+    def sync(self):
+        self._check(self.L.ptx_sync(self._h), "ptx_sync")
+
+    # -- RenderLoop::render_pass (renderloop/parallel.rs:171-194) -----------------
+    def render_pass(self, scene, camera, renderer, width, height, sample_index):
+        self._bind(scene, camera)
+        out = np.zeros((height, width, 3), dtype=np.float32)
+        if isinstance(renderer, UnshadedRenderer):
+            self._check(self.L.ptx_render_pass_unshaded(self._h, width, height, sample_index, _p(out)), "ptx_render_pass_unshaded")
+        else:
+            self._check(self.L.ptx_render_pass(self._h, width, height, sample_index, renderer.max_bounces, _p(out)), "ptx_render_pass")
+        return out
+
+    # -- render_first_pass_with_aov (renderloop/parallel.rs:125-168) --------------
+    def render_first_pass_with_aov(self, scene, camera, renderer, width, height):
+        self._bind(scene, camera)
+        out, alb, nrm = (np.zeros((height, width, 3), dtype=np.float32) for _ in range(3))
+        self._check(self.L.ptx_render_first_pass_aov(self._h, width, height, renderer.max_bounces, _p(out), _p(alb), _p(nrm)),
+                    "ptx_render_first_pass_aov")
+        return out, (alb, nrm)
+
+    # -- render_pixels (renderloop/parallel.rs:58-78) ------------------------------
+    def render_pixels(self, scene, camera, renderer, width, height, pixels):
+        self._bind(scene, camera)
+        xys = np.ascontiguousarray(pixels, dtype=np.uint32).reshape(-1, 3)
+        out = np.zeros((len(xys), 3), dtype=np.float32)
+        if len(xys):
+            self._check(self.L.ptx_render_pixels(self._h, width, height, _p(xys), len(xys), renderer.max_bounces, _p(out)),
+                        "ptx_render_pixels")
+        return out
+
+    # -- render_adaptive_pass (renderloop/parallel.rs:80-123) ----------------------
+    def render_adaptive_pass(self, scene, camera, renderer, framebuffer, config):
+        self._bind(scene, camera)
+        framebuffer._require(self)
+        mx = config.max_samples_per_pass
+        if mx is None:
+            mx = framebuffer.width * framebuffer.height
+        cfg = abi.PtxAdaptiveConfig(config.min_samples, config.variance_threshold, mx)
+        n = C.c_uint64(0)
+        self._check(self.L.ptx_fb_adaptive_pass(self._h, C.byref(cfg), renderer.max_bounces, C.byref(n)), "ptx_fb_adaptive_pass")
+        return int(n.value)
+
+    # -- Scene::hit / hit_any on a caller's batch (scene.rs:44-50) -----------------
+    def trace_closest(self, scene, rays):
+        self._bind(scene, None)
+        rays = np.ascontiguousarray(rays, dtype=abi.ray_dtype())
+        out = np.zeros(len(rays), dtype=abi.hit_dtype())
+        if len(rays):
+            self._check(self.L.ptx_trace_batch(self._h, _p(rays), len(rays), abi.PTX_TRACE_CLOSEST, _p(out), None), "ptx_trace_batch")
+        return out
+
+    def trace_any(self, scene, rays):
+        self._bind(scene, None)
+        rays = np.ascontiguousarray(rays, dtype=abi.ray_dtype())
+        out = np.zeros(len(rays), dtype=np.uint8)
+        if len(rays):
+            self._check(self.L.ptx_trace_batch(self._h, _p(rays), len(rays), abi.PTX_TRACE_ANY, None, _p(out)), "ptx_trace_batch")
+        return out
+
+    def primary_rays(self, scene, camera, width, height, sample_index):
+        self._bind(scene, camera)
+        out = np.zeros(width * height, dtype=abi.ray_dtype())
+        self._check(self.L.ptx_generate_primary_rays(self._h, width, height, sample_index, _p(out)), "ptx_generate_primary_rays")
+        return out
+
+    # -- measurement -----------------------------------------------------------------
+    def set_counting(self, on):
+        self._check(self.L.ptx_set_counting(self._h, 1 if on else 0), "ptx_set_counting")
+
+    def reset_counters(self):
+        self._check(self.L.ptx_reset_counters(self._h), "ptx_reset_counters")
+
+    def counters(self):
+        c = abi.PtxCounters()
+        self._check(self.L.ptx_get_counters(self._h, C.byref(c)), "ptx_get_counters")
+        return c.as_dict()
+
+    def set_profiling(self, on):
+        self._check(self.L.ptx_set_profiling(self._h, 1 if on else 0), "ptx_set_profiling")
+
+    def reset_timings(self):
+        self._check(self.L.ptx_reset_timings(self._h), "ptx_reset_timings")
+
+    def timings(self):
+        t = abi.PtxTimings()
+        self._check(self.L.ptx_get_timings(self._h, C.byref(t)), "ptx_get_timings")
+        return {n: getattr(t, n) for n, _ in abi.PtxTimings._fields_}
+
+
+class DeviceFramebuffer:
+    """`Framebuffer` / `AdaptiveFramebuffer` (framebuffer.rs:10-60, 76-229) kept in HBM.
+
+    One framebuffer per render loop (the context owns it): `accumulate` never
+    sees host pixels — `render_passes` is `for sample { render_pass; accumulate }`
+    (main.rs:124-133) entirely on the device.
+    """
+
+    def __init__(self, loop, width, height, adaptive=True):
+        self.loop, self.width, self.height, self.adaptive = loop, int(width), int(height), bool(adaptive)
+        self.reset()
+
+    def _require(self, loop):
+        if loop is not self.loop:
+            raise RenderCoreError("framebuffer belongs to another render loop")
+
+    def reset(self):
+        self.loop._check(self.loop.L.ptx_fb_reset(self.loop._h, self.width, self.height, 1 if self.adaptive else 0), "ptx_fb_reset")
+
+    def render_passes(self, scene, camera, renderer, first_sample, count):
+        self.loop._bind(scene, camera)
+        self.loop._check(self.loop.L.ptx_fb_render_passes(self.loop._h, first_sample, count, renderer.max_bounces), "ptx_fb_render_passes")
+
+    def stats(self):
+        mn, mx, tot = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+        self.loop._check(self.loop.L.ptx_fb_stats(self.loop._h, C.byref(mn), C.byref(mx), C.byref(tot)), "ptx_fb_stats")
+        return int(mn.value), int(mx.value), int(tot.value)
+
+    def min_sample_count(self):
+        return self.stats()[0]
+
+    def max_sample_count(self):
+        return self.stats()[1]
+
+    def total_samples(self):
+        return self.stats()[2]
+
+    def read(self):
+        s = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        q = np.zeros((self.height, self.width, 3), dtype=np.float32) if self.adaptive else None
+        c = np.zeros((self.height, self.width), dtype=np.uint32)
+        self.loop._check(self.loop.L.ptx_fb_read(self.loop._h, _p(s), _p(q), _p(c)), "ptx_fb_read")
+        return s, q, c
+
+    def to_color_buffer(self):
+        m = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        self.loop._check(self.loop.L.ptx_fb_read_mean(self.loop._h, _p(m)), "ptx_fb_read_mean")
+        return m
+
+    def export_dev(self, d_sum_ptr, d_sum_sq_ptr, d_counts_ptr):
+        """Copy the accumulators into caller-owned device memory (raw pointers, e.g. torch `data_ptr()`)."""
+        self.loop._check(self.loop.L.ptx_fb_export_dev(self.loop._h, d_sum_ptr, d_sum_sq_ptr, d_counts_ptr), "ptx_fb_export_dev")
