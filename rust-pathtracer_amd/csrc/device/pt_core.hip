@@ -1,0 +1,1561 @@
+// pt_core.hip — gfx950 wavefront kernels + the C ABI of include/ptx_core.h.
+//
+// Kernel pipeline of one pass (one sample for every path slot):
+//   k_raygen    blue-noise jitter -> camera ray -> RNG seed      (R1-R3)
+//   loop over path-tracing iterations:
+//     k_extend    closest-hit traversal for every live path      (T1-T13)
+//     k_shade     pending adds, hit data, material, MIS integrator step, SSS
+//                 state machine; pushes shadow rays / next / finished queues
+//                 with wave64 ballot + mbcnt prefix compaction     (I1-I13)
+//     k_shadow    any-hit traversal for the NEE shadow-ray queue   (T7)
+//     k_finalize  finished paths: apply pending adds, clamp_radiance,
+//                 accumulate into sum / sum_sq / count             (A1/A2)
+// Path state is AoS-of-float4 in HBM (one 16-byte access per field group per
+// lane, so sparse survivors touch few lines); queues hold path-slot indices.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hipcub/hipcub.hpp>
+
+#include "pt_shade.h"
+#include "pt_traverse.h"
+
+using namespace ptd;
+
+namespace {
+
+// ============================================================== path state =====
+constexpr uint32_t ST_NORMAL = 0, ST_THICK = 1, ST_WALK = 2;
+constexpr uint32_t FL_BOUNCE_MASK = 0xFFu, FL_SPECULAR = 1u << 8, FL_STATE_SHIFT = 9, FL_STATE_MASK = 3u << 9,
+                   FL_FIRST_HIT = 1u << 11, FL_STEP_SHIFT = 16, FL_STEP_MASK = 0xFFu << 16;
+
+struct PathArrays {
+    float4* ray_o;     // origin.xyz, t_max
+    float4* ray_d;     // direction.xyz, last_brdf_pdf
+    float4* thr;       // throughput.xyz, flags
+    float4* rad;       // radiance.xyz, pixel index
+    uint2* rng;        // PCG state
+    float4* hit;       // t, u, v, inst
+    uint32_t* hit_tri;
+    float4* sh_o;      // shadow-ray origin
+    float4* sh_d;      // sky shadow-ray direction
+    float4* c_sun;     // pending contribution behind the sun shadow ray
+    float4* c_sky;     // pending contribution behind the sky shadow ray
+    float4* c_post;    // BSDF-sampled sun hit (added after the NEE terms, pathtracer.rs:319-322)
+    float4* w_t;       // SSS walk throughput.xyz, thickness_scale
+    float4* w_b;       // base_color.xyz of the entry vertex, material id
+    float4* aov_a;     // first-hit albedo (AOV pass only)
+    float4* aov_n;
+    uint32_t* sample;  // sample_index of the slot
+};
+
+// per-iteration counter block
+struct IterCtr { uint32_t n_active, n_shadow, n_final, w_extend, w_shadow, pad0, pad1, pad2; };
+constexpr uint32_t MAX_ITERS = 4096;
+
+constexpr int TRACE_GRID = 256 * 16;       // persistent waves: 16 per CU
+constexpr int SHADE_BLOCK = 256;
+
+struct Target {
+    float* out_rgb;        // by pixel (or by slot) *3, overwritten          (render_pass / render_pixels)
+    float* out_albedo;     // AOV, by pixel
+    float* out_normal;
+    float* sum;            // framebuffer accumulate (+=)
+    float* sum_sq;
+    uint32_t* counts;
+    uint32_t by_slot;
+};
+
+// ---- wave64 ballot / prefix queue push ------------------------------------------
+PT_DEV void queue_push(uint32_t* q, uint32_t* counter, bool pred, uint32_t value) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (pred) q[base + rank] = value;
+}
+
+PT_DEV void wave_add(unsigned long long* dst, uint32_t v) {
+    // wave reduction then one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63u) == 0u && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+PT_DEV StackRef make_stack(uint2* ovf) {
+    StackRef st;
+    st.ovf = ovf + (size_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    st.ovf_stride = (uint32_t)(gridDim.x * TRACE_BLOCK);
+    return st;
+}
+
+PT_DEV void flush_lane_cnt(DevCounters* dc, const LaneCnt& lc, uint32_t rays, bool any) {
+    wave_add(&dc->v[any ? C_RAYS_ANY : C_RAYS_CLOSEST], rays);
+    wave_add(&dc->v[C_NODE_VISITS], lc.node_visits);
+    wave_add(&dc->v[C_NODE_CHILDREN], lc.node_children);
+    wave_add(&dc->v[C_PRIM_INDEX_READS], lc.prim_reads);
+    wave_add(&dc->v[C_TRI_TESTS], lc.tri_tests);
+    wave_add(&dc->v[C_INST_ENTRIES], lc.inst_entries);
+    wave_add(&dc->v[C_INST_HITS], lc.inst_hits);
+}
+
+// ================================================================ kernels ======
+
+// ---- ray batches (ptx_trace_batch) ------------------------------------------------
+template <bool ANY, bool CNT>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_batch(SceneDev S, const PtxRay* rays, uint64_t n, PtxHitRecord* out_hits,
+                                                             uint8_t* out_any, uint2* ovf, DevCounters* dc, uint32_t* err) {
+    const StackRef st = make_stack(ovf);
+    LaneCnt lc = {0, 0, 0, 0, 0, 0};
+    uint32_t nrays = 0, e = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TRACE_BLOCK) {
+        const PtxRay r = rays[i];
+        Hit h;
+        h.inst = PTX_MISS; h.tri = PTX_MISS; h.t = PT_INF; h.u = 0.0f; h.v = 0.0f;
+        const bool res = trace_ray<ANY, CNT>(S, v3(r.origin[0], r.origin[1], r.origin[2]), v3(r.direction[0], r.direction[1], r.direction[2]),
+                                             r.t_max, st, h, lc, e);
+        nrays++;
+        if (ANY) out_any[i] = res ? 1 : 0;
+        else { PtxHitRecord o; o.inst_idx = h.inst; o.tri_idx = h.tri; o.t = h.t; o.u = h.u; o.v = h.v; out_hits[i] = o; }
+    }
+    if (e) atomicOr(err, e);
+    if (CNT) flush_lane_cnt(dc, lc, nrays, ANY);
+}
+
+// ---- ray-gen: render_pixel up to renderer.render (renderloop/parallel.rs:31-56) ----
+__global__ void k_raygen(SceneDev S, CameraDev cam, PathArrays P, const uint32_t* wl_pixel, const uint32_t* wl_sample,
+                         const uint32_t* fb_counts, uint32_t uniform_sample, uint32_t n, uint32_t width, uint32_t height,
+                         uint32_t* q, IterCtr* ctr0, uint32_t aov, PtxRay* out_rays) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && ctr0) ctr0->n_active = n;
+    if (i >= n) return;
+    const uint32_t pixel = wl_pixel[i];
+    // sample index: explicit list (render_pixels), the pixel's own count (adaptive), or the pass's
+    const uint32_t sample_index = wl_sample ? wl_sample[i] : (fb_counts ? fb_counts[pixel] : uniform_sample);
+    const uint32_t x = pixel % width, y = pixel / width;
+    float px, py, lx, ly;
+    bluenoise_sample(S.bn_pixel, S.bn_size, x, y, sample_index, &px, &py);
+    bluenoise_sample(S.bn_lens, S.bn_size, x, y, sample_index, &lx, &ly);
+    const float u = ((float)x + px) / (float)width;
+    const float v = ((float)y + py) / (float)height;
+    V3 o, d;
+    generate_ray_dof(cam, u, v, lx, ly, &o, &d);
+    if (out_rays) {
+        PtxRay r;
+        r.origin[0] = o.x; r.origin[1] = o.y; r.origin[2] = o.z;
+        r.direction[0] = d.x; r.direction[1] = d.y; r.direction[2] = d.z;
+        r.t_max = PT_INF;
+        out_rays[i] = r;
+        return;
+    }
+    const Rng rng = rng_new(path_seed(o, d, sample_index));
+    P.ray_o[i] = make_float4(o.x, o.y, o.z, PT_INF);
+    P.ray_d[i] = make_float4(d.x, d.y, d.z, 0.0f);
+    P.thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(aov ? FL_FIRST_HIT : 0u));
+    P.rad[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(pixel));
+    P.rng[i] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    P.c_sun[i] = z; P.c_sky[i] = z; P.c_post[i] = z;
+    P.sample[i] = sample_index;
+    if (aov) { P.aov_a[i] = z; P.aov_n[i] = z; }
+    q[i] = i;
+}
+
+// ---- extend: Scene::hit for every live path ----------------------------------------
+template <bool CNT>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_extend(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
+                                                        DevCounters* dc, uint32_t* err) {
+    const StackRef st = make_stack(ovf);
+    const uint32_t n = ctr->n_active;
+    LaneCnt lc = {0, 0, 0, 0, 0, 0};
+    uint32_t nrays = 0, e = 0;
+    for (;;) {
+        uint32_t chunk = 0;
+        if (threadIdx.x == 0) chunk = atomicAdd(&ctr->w_extend, (uint32_t)TRACE_BLOCK);
+        chunk = __shfl(chunk, 0);
+        if (chunk >= n) break;
+        const uint32_t i = chunk + threadIdx.x;
+        if (i < n) {
+            const uint32_t p = q[i];
+            const float4 ro = P.ray_o[p], rd = P.ray_d[p];
+            Hit h;
+            h.inst = PTX_MISS; h.tri = PTX_MISS; h.t = PT_INF; h.u = 0.0f; h.v = 0.0f;
+            trace_ray<false, CNT>(S, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, st, h, lc, e);
+            nrays++;
+            P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.inst));
+            P.hit_tri[p] = h.tri;
+        }
+    }
+    if (e) atomicOr(err, e);
+    if (CNT) flush_lane_cnt(dc, lc, nrays, false);
+}
+
+// ---- shadow: Scene::hit_any for the NEE queue ---------------------------------------
+template <bool CNT>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneDev S, PathArrays P, const uint32_t* qs, IterCtr* ctr, uint2* ovf,
+                                                        DevCounters* dc, uint32_t* err) {
+    const StackRef st = make_stack(ovf);
+    const uint32_t n = ctr->n_shadow;
+    LaneCnt lc = {0, 0, 0, 0, 0, 0};
+    uint32_t nrays = 0, e = 0;
+    for (;;) {
+        uint32_t chunk = 0;
+        if (threadIdx.x == 0) chunk = atomicAdd(&ctr->w_shadow, (uint32_t)TRACE_BLOCK);
+        chunk = __shfl(chunk, 0);
+        if (chunk >= n) break;
+        const uint32_t i = chunk + threadIdx.x;
+        if (i < n) {
+            const uint32_t entry = qs[i];
+            const uint32_t p = entry >> 1, kind = entry & 1u;
+            const float4 so = P.sh_o[p];
+            V3 d;
+            if (kind == 0u) d = v3(S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]);
+            else { const float4 sd = P.sh_d[p]; d = v3(sd.x, sd.y, sd.z); }
+            Hit h;
+            const bool occluded = trace_ray<true, CNT>(S, v3(so.x, so.y, so.z), d, PT_INF, st, h, lc, e);
+            nrays++;
+            if (occluded) {
+                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (kind == 0u) P.c_sun[p] = z; else P.c_sky[p] = z;
+            }
+        }
+    }
+    if (e) atomicOr(err, e);
+    if (CNT) flush_lane_cnt(dc, lc, nrays, true);
+}
+
+// ---- shade: one step of trace_inner's state machine ---------------------------------
+struct WalkCtx { V3 sigma_t, sigma_s; };
+PT_DEV WalkCtx walk_ctx(const PtxMaterial& m, float scale) {
+    // scaled_radius = radius * thickness_scale (pathtracer.rs:218-219); sigma (subsurface.rs:67-72)
+    const V3 radius = v3(m.subsurface_radius[0], m.subsurface_radius[1], m.subsurface_radius[2]) * scale;
+    WalkCtx w;
+    w.sigma_t = v3(1.0f / f_max(radius.x, 0.0001f), 1.0f / f_max(radius.y, 0.0001f), 1.0f / f_max(radius.z, 0.0001f));
+    w.sigma_s = w.sigma_t * v3(m.subsurface_albedo[0], m.subsurface_albedo[1], m.subsurface_albedo[2]);
+    return w;
+}
+
+template <bool CNT>
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, PathArrays P, const uint32_t* q, uint32_t* q_next, uint32_t* q_shadow,
+                                                       uint32_t* q_final, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
+                                                       DevCounters* dc) {
+    const uint32_t n = ctr->n_active;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        const bool active = i < n;
+        bool alive = false, push_sun = false, push_sky = false;
+        uint32_t p = 0;
+        if (active) {
+            p = q[i];
+            const float4 ro4 = P.ray_o[p], rd4 = P.ray_d[p], th4 = P.thr[p], ra4 = P.rad[p], hi4 = P.hit[p];
+            const uint2 rs = P.rng[p];
+            Rng rng;
+            rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+            V3 ro = v3(ro4.x, ro4.y, ro4.z), rd = v3(rd4.x, rd4.y, rd4.z);
+            float ray_tmax = ro4.w, last_pdf = rd4.w;
+            V3 T = v3(th4.x, th4.y, th4.z), L = v3(ra4.x, ra4.y, ra4.z);
+            uint32_t flags = __float_as_uint(th4.w);
+            uint32_t bounce = flags & FL_BOUNCE_MASK;
+            bool last_spec = (flags & FL_SPECULAR) != 0;
+            uint32_t state = (flags & FL_STATE_MASK) >> FL_STATE_SHIFT;
+            bool first_hit = (flags & FL_FIRST_HIT) != 0;
+            uint32_t step = (flags & FL_STEP_MASK) >> FL_STEP_SHIFT;
+            const uint32_t h_inst = __float_as_uint(hi4.w);
+            const bool has_hit = h_inst != PTX_MISS;
+
+            // pending adds of the previous step, in the reference's order (NEE sun, NEE sky, BSDF-sampled sun)
+            { const float4 a = P.c_sun[p], b = P.c_sky[p], c = P.c_post[p];
+              L = L + v3(a.x, a.y, a.z); L = L + v3(b.x, b.y, b.z); L = L + v3(c.x, c.y, c.z); }
+            V3 c_sun = splat(0.0f), c_sky = splat(0.0f), c_post = splat(0.0f);
+            V3 sh_o = splat(0.0f), sh_d = splat(0.0f);
+            alive = true;
+            const V3 sun_dir = v3(S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]);
+            const V3 sun_color = v3(S.sun_color[0], S.sun_color[1], S.sun_color[2]);
+
+            bool begin_walk_step = false, sss_exit = false;
+            V3 w_pos = ro, w_dir = rd, wt = splat(1.0f), exit_point = splat(0.0f), exit_n = splat(0.0f), sss_base = splat(0.0f);
+            float w_scale = 1.0f;
+            uint32_t w_mat = 0;
+
+            if (state == ST_NORMAL) {
+                if (!has_hit) {
+                    // miss (pathtracer.rs:118-134)
+                    const V3 sky_radiance = sky_sample(S, rd, sc);
+                    if (bounce == 0u) {
+                        L = L + T * sky_radiance;
+                        if (first_hit) {
+                            const V3 a = clamp01(sky_radiance), nn = -rd;
+                            P.aov_a[p] = make_float4(a.x, a.y, a.z, 0.0f);
+                            P.aov_n[p] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+                        }
+                    } else if (last_spec) {
+                        L = L + T * sky_radiance;
+                    } else {
+                        const float spdf = sky_pdf(S, rd, sc);
+                        const float mis = mis_weight(last_pdf, spdf);
+                        L = L + T * sky_radiance * mis;
+                    }
+                    alive = false;
+                } else {
+                    const HitData hit = compute_hit_data(S, h_inst, P.hit_tri[p], hi4.x, hi4.y, hi4.z);
+                    if (CNT) { sc.hitdata++; sc.material++; }
+                    const PtxMaterial& material = S.materials[hit.material_id];
+                    const SampledMaterial mat = sample_material(S, material, hit, sc);
+                    if (first_hit) {
+                        const V3 nn = mat.normal * 0.5f + splat(0.5f);
+                        P.aov_a[p] = make_float4(mat.base_color.x, mat.base_color.y, mat.base_color.z, 0.0f);
+                        P.aov_n[p] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+                        first_hit = false;
+                    }
+                    L = L + T * mat.emissive;
+
+                    const bool front_face = dot(rd, hit.geo_normal) < 0.0f;
+                    const V3 geo_n = front_face ? hit.geo_normal : -hit.geo_normal;
+                    const V3 v = -normalize(rd);
+                    const V3 shading_n = (dot(mat.normal, geo_n) > 0.0f) ? mat.normal : -mat.normal;
+                    const V3 nrm = fix_shading_normal(shading_n, geo_n, v);
+                    const V3 hit_point = ro + rd * hit.t;
+                    const float transmission = material.transmission;
+                    bool handled = false;
+
+                    if (transmission > 0.0f && rng.next() < transmission) {
+                        // sample_transmission (pathtracer.rs:328-348)
+                        const float ior = material.ior;
+                        const float eta = front_face ? 1.0f / ior : ior;
+                        const float cos_theta = f_min(dot(-rd, nrm), 1.0f);
+                        const float fresnel = fresnel_dielectric(cos_theta, ior);
+                        V3 new_dir, offset_normal;
+                        if (rng.next() < fresnel) { new_dir = reflect(rd, nrm); offset_normal = nrm; }
+                        else {
+                            V3 refr;
+                            if (refract(rd, nrm, eta, &refr)) { new_dir = normalize(refr); offset_normal = -nrm; }
+                            else { new_dir = reflect(rd, nrm); offset_normal = nrm; }
+                        }
+                        T = T * mat.base_color;
+                        if (!russian_roulette(rng, T, bounce)) alive = false;
+                        else { ro = hit_point + offset_normal * RAY_EPSILON; rd = new_dir; ray_tmax = PT_INF; last_spec = true; bounce++; }
+                        handled = true;
+                    }
+                    if (!handled) {
+                        const float sss_prob = (material.subsurface > 0.0f && front_face) ? material.subsurface : 0.0f;
+                        if (sss_prob > 0.0f && rng.next() < sss_prob) {
+                            handled = true;
+                            T = T / sss_prob;
+                            const float cos_theta = f_min(dot(v, nrm), 1.0f);
+                            const float fresnel = fresnel_dielectric(cos_theta, material.ior);
+                            bool do_reflect = false;
+                            V3 refr = splat(0.0f);
+                            if (rng.next() < fresnel) do_reflect = true;
+                            else if (!refract(-v, nrm, 1.0f / material.ior, &refr)) do_reflect = true;
+                            if (do_reflect) {
+                                rd = reflect(-v, nrm);
+                                ro = hit_point + nrm * RAY_EPSILON; ray_tmax = PT_INF;
+                                last_spec = true; bounce++;
+                            } else {
+                                const V3 entry_dir = normalize(refr);
+                                T = T * v3(material.subsurface_entry_tint[0], material.subsurface_entry_tint[1], material.subsurface_entry_tint[2]);
+                                ro = hit_point - nrm * RAY_EPSILON;   // entry_point; thickness ray (pathtracer.rs:205-207)
+                                rd = entry_dir; ray_tmax = PT_INF;
+                                state = ST_THICK;
+                                P.w_b[p] = make_float4(mat.base_color.x, mat.base_color.y, mat.base_color.z, __uint_as_float(hit.material_id));
+                            }
+                        } else if (sss_prob > 0.0f) {
+                            T = T / (1.0f - sss_prob);
+                        }
+                    }
+                    if (!handled) {
+                        last_spec = false;
+                        const float alpha = mat.roughness * mat.roughness;
+                        const V3 f0 = lerp(splat(0.04f), mat.base_color, mat.metallic);
+                        const V3 diffuse_color = mat.base_color * (1.0f - mat.metallic);
+                        V3 tb, bb;
+                        build_basis(nrm, &tb, &bb);
+                        const float n_dot_v = f_max(dot(v, nrm), 0.001f);
+                        const float spec_prob = compute_spec_prob(n_dot_v, f0, diffuse_color);
+                        sh_o = hit_point + geo_n * RAY_EPSILON;
+
+                        // sample_direct_light (pathtracer.rs:372-400): visibility is resolved by k_shadow
+                        if (S.sun_enabled) {
+                            const float n_dot_l = dot(nrm, sun_dir);
+                            if (n_dot_l > 0.0f) {
+                                const V3 brdf = evaluate_brdf(v, sun_dir, nrm, alpha, f0, diffuse_color);
+                                float n_dot_h, v_dot_h;
+                                half_vector_dots(v, sun_dir, nrm, &n_dot_h, &v_dot_h);
+                                const float brdf_pdf = pdf_brdf(n_dot_l, n_dot_h, v_dot_h, alpha, spec_prob);
+                                const float mis = mis_weight(S.sun_pdf, brdf_pdf);
+                                c_sun = T * brdf * sun_color * mis;
+                                push_sun = true;
+                            }
+                        }
+                        // sample_sky_light (pathtracer.rs:402-435)
+                        {
+                            const float u1 = rng.next();
+                            const float u2 = rng.next();
+                            const SkySample ss = sky_sample_direction(S, u1, u2, sc);
+                            const V3 l = ss.direction;
+                            const float n_dot_l = dot(nrm, l);
+                            if (!(n_dot_l <= 0.0f || ss.pdf <= 0.0f)) {
+                                const V3 brdf = evaluate_brdf(v, l, nrm, alpha, f0, diffuse_color);
+                                float n_dot_h, v_dot_h;
+                                half_vector_dots(v, l, nrm, &n_dot_h, &v_dot_h);
+                                const float brdf_pdf = pdf_brdf(n_dot_l, n_dot_h, v_dot_h, alpha, spec_prob);
+                                const float mis = mis_weight(ss.pdf, brdf_pdf);
+                                const V3 sky_contribution = clamp_radiance(ss.radiance * safe_inv_pdf(ss.pdf));
+                                c_sky = T * brdf * sky_contribution * mis;
+                                sh_d = l;
+                                push_sky = true;
+                            }
+                        }
+                        // sample_brdf (pathtracer.rs:437-479)
+                        V3 new_dir = splat(0.0f), weight = splat(0.0f);
+                        float pdf = 0.0f;
+                        bool ok = true;
+                        if (rng.next() < spec_prob) {
+                            const float u1 = rng.next();
+                            const float u2 = rng.next();
+                            const V3 h = to_world(sample_ggx(u1, u2, alpha), tb, bb, nrm);
+                            const V3 l = normalize(2.0f * dot(v, h) * h - v);
+                            const float n_dot_l = dot(nrm, l);
+                            if (n_dot_l <= 0.0f) ok = false;
+                            else {
+                                const float n_dot_h = f_max(dot(nrm, h), 0.001f);
+                                const float v_dot_h = f_max(dot(v, h), 0.001f);
+                                const V3 f = fresnel_schlick(v_dot_h, f0);
+                                const float g = ggx_g(n_dot_l, n_dot_v, alpha);
+                                weight = f * g * v_dot_h / (n_dot_v * n_dot_h * spec_prob);
+                                pdf = pdf_brdf(n_dot_l, n_dot_h, v_dot_h, alpha, spec_prob);
+                                new_dir = l;
+                            }
+                        } else {
+                            const float u1 = rng.next();
+                            const float u2 = rng.next();
+                            const V3 l = to_world(sample_cosine_hemisphere(u1, u2), tb, bb, nrm);
+                            const float n_dot_l = f_max(dot(nrm, l), 0.001f);
+                            float n_dot_h, v_dot_h;
+                            half_vector_dots(v, l, nrm, &n_dot_h, &v_dot_h);
+                            const V3 f = fresnel_schlick(v_dot_h, f0);
+                            weight = diffuse_color * (splat(1.0f) - f) / (1.0f - spec_prob);
+                            pdf = pdf_brdf(n_dot_l, n_dot_h, v_dot_h, alpha, spec_prob);
+                            new_dir = l;
+                        }
+                        if (!ok) alive = false;
+                        else {
+                            T = T * weight;
+                            if (!russian_roulette(rng, T, bounce)) alive = false;
+                            else {
+                                ro = hit_point + geo_n * RAY_EPSILON; rd = new_dir; ray_tmax = PT_INF;
+                                last_pdf = pdf;
+                                if (S.sun_enabled && dot(new_dir, sun_dir) >= S.sun_cos_angle) {
+                                    const float mis = mis_weight(pdf, S.sun_pdf);
+                                    c_post = T * sun_color * mis;
+                                }
+                                bounce++;
+                            }
+                        }
+                    }
+                }
+            } else {
+                // ---- subsurface states (pathtracer.rs:207-229, subsurface.rs:58-160)
+                const float4 wb4 = P.w_b[p];
+                sss_base = v3(wb4.x, wb4.y, wb4.z);
+                w_mat = __float_as_uint(wb4.w);
+                const PtxMaterial& material = S.materials[w_mat];
+                if (state == ST_THICK) {
+                    float thickness = 1.0f;
+                    if (has_hit) {
+                        const HitData bh = compute_hit_data(S, h_inst, P.hit_tri[p], hi4.x, hi4.y, hi4.z);
+                        if (CNT) sc.hitdata++;
+                        if (dot(rd, bh.normal) > 0.0f) thickness = bh.t;
+                    }
+                    w_scale = f_clamp(thickness / 1.0f, 0.1f, 2.0f);
+                    wt = splat(1.0f);
+                    step = 0;
+                    begin_walk_step = true;
+                } else {
+                    const float4 wt4 = P.w_t[p];
+                    wt = v3(wt4.x, wt4.y, wt4.z);
+                    w_scale = wt4.w;
+                    const WalkCtx wc = walk_ctx(material, w_scale);
+                    const V3 weights = wt * wc.sigma_s;
+                    const float sum_weights = weights.x + weights.y + weights.z;
+                    const float dist = ray_tmax;
+                    bool walk_done = false;
+                    if (has_hit) {
+                        const HitData wh = compute_hit_data(S, h_inst, P.hit_tri[p], hi4.x, hi4.y, hi4.z);
+                        if (CNT) sc.hitdata++;
+                        const V3 hit_point = w_pos + w_dir * wh.t;
+                        if (dot(w_dir, wh.normal) > 0.0f) {
+                            const float t = wh.t;
+                            const V3 tr = v3(d_expf(-wc.sigma_t.x * t), d_expf(-wc.sigma_t.y * t), d_expf(-wc.sigma_t.z * t));
+                            const float pdf_sum = (tr.x * (weights.x / sum_weights) + tr.y * (weights.y / sum_weights)) + tr.z * (weights.z / sum_weights);
+                            wt = wt * (tr / f_max(pdf_sum, 1e-10f));
+                            exit_point = hit_point; exit_n = wh.normal;
+                            sss_exit = true;
+                        } else {
+                            w_pos = hit_point + w_dir * RAY_EPSILON;
+                            begin_walk_step = true;
+                        }
+                        walk_done = true;
+                    }
+                    if (!walk_done) {
+                        w_pos = w_pos + w_dir * dist;
+                        const V3 tr = v3(d_expf(-wc.sigma_t.x * dist), d_expf(-wc.sigma_t.y * dist), d_expf(-wc.sigma_t.z * dist));
+                        const float pdf_sum = (wc.sigma_t.x * tr.x * (weights.x / sum_weights) + wc.sigma_t.y * tr.y * (weights.y / sum_weights)) +
+                                              wc.sigma_t.z * tr.z * (weights.z / sum_weights);
+                        wt = wt * (tr * wc.sigma_s / f_max(pdf_sum, 1e-10f));
+                        const float max_tp = max_element(wt);
+                        bool dead = false;
+                        if (max_tp < 0.1f) {
+                            const float survive = f_min(max_tp * 10.0f, 1.0f);
+                            if (rng.next() > survive) dead = true;
+                            else wt = wt / survive;
+                        }
+                        if (!dead && (!is_finite(wt) || max_tp > 1000.0f)) dead = true;
+                        if (dead) alive = false;   // random_walk_subsurface -> None -> break
+                        else {
+                            // sample_hg_phase (subsurface.rs:41-56)
+                            const float g = material.subsurface_anisotropy;
+                            float cos_theta;
+                            if (fabsf(g) < 0.001f) cos_theta = 1.0f - 2.0f * rng.next();
+                            else {
+                                const float g2 = g * g;
+                                const float sqr = (1.0f - g2) / (1.0f - g + 2.0f * g * rng.next());
+                                cos_theta = f_clamp((1.0f + g2 - sqr * sqr) / (2.0f * g), -1.0f, 1.0f);
+                            }
+                            const float sin_theta = sqrtf(f_max(1.0f - cos_theta * cos_theta, 0.0f));
+                            const float phi = 2.0f * PT_PI * rng.next();
+                            const V3 nn = -w_dir;
+                            V3 tb, bb;
+                            build_basis(nn, &tb, &bb);
+                            float sp, cp;
+                            d_sincosf(phi, &sp, &cp);
+                            w_dir = to_world(v3(sin_theta * cp, sin_theta * sp, cos_theta), tb, bb, nn);
+                            begin_walk_step = true;
+                        }
+                    }
+                }
+                if (begin_walk_step) {
+                    // head of one `for _ in 0..SSS_MAX_STEPS` iteration (subsurface.rs:78-98)
+                    if (step >= 64u) alive = false;
+                    else {
+                        if (CNT) sc.sss_steps++;
+                        const WalkCtx wc = walk_ctx(material, w_scale);
+                        const V3 weights = wt * wc.sigma_s;
+                        const float sum_weights = weights.x + weights.y + weights.z;
+                        if (sum_weights < 1e-10f) alive = false;
+                        else {
+                            const float r = rng.next() * sum_weights;
+                            const int channel = (r < weights.x) ? 0 : ((r < weights.x + weights.y) ? 1 : 2);
+                            const float sigma_t_c = comp(wc.sigma_t, channel);
+                            const float dist = -d_logf(f_max(rng.next(), 1e-10f)) / sigma_t_c;
+                            ro = w_pos; rd = w_dir; ray_tmax = dist;
+                            state = ST_WALK;
+                            step++;
+                            P.w_t[p] = make_float4(wt.x, wt.y, wt.z, w_scale);
+                        }
+                    }
+                }
+                if (sss_exit) {
+                    // success branch of trace_inner (pathtracer.rs:230-271)
+                    T = T * (sss_base * wt * v3(material.subsurface_exit_tint[0], material.subsurface_exit_tint[1], material.subsurface_exit_tint[2]));
+                    if (!russian_roulette(rng, T, bounce)) alive = false;
+                    else {
+                        const V3 diffuse_brdf = sss_base / PT_PI;
+                        sh_o = exit_point + exit_n * RAY_EPSILON;
+                        if (S.sun_enabled) {
+                            const float n_dot_l = dot(exit_n, sun_dir);
+                            if (n_dot_l > 0.0f) { c_sun = T * diffuse_brdf * sun_color * n_dot_l; push_sun = true; }
+                        }
+                        {
+                            const float u1 = rng.next();
+                            const float u2 = rng.next();
+                            const SkySample ss = sky_sample_direction(S, u1, u2, sc);
+                            const float n_dot_l = dot(exit_n, ss.direction);
+                            if (n_dot_l > 0.0f && ss.pdf > 0.0f) {
+                                const V3 sky_contribution = clamp_radiance(ss.radiance * safe_inv_pdf(ss.pdf));
+                                c_sky = T * diffuse_brdf * sky_contribution * n_dot_l;
+                                sh_d = ss.direction;
+                                push_sky = true;
+                            }
+                        }
+                        V3 et, eb;
+                        build_basis(exit_n, &et, &eb);
+                        const float u1 = rng.next();
+                        const float u2 = rng.next();
+                        const V3 exit_dir = to_world(sample_cosine_hemisphere(u1, u2), et, eb, exit_n);
+                        ro = exit_point + exit_n * RAY_EPSILON; rd = exit_dir; ray_tmax = PT_INF;
+                        last_spec = false;
+                        last_pdf = pdf_cosine(f_max(dot(exit_n, exit_dir), 0.001f));
+                        state = ST_NORMAL;
+                        bounce++;
+                    }
+                }
+            }
+
+            // `for bounce in 0..MAX_BOUNCES` ran out (pathtracer.rs:117)
+            if (alive && state == ST_NORMAL && bounce >= max_bounces) alive = false;
+
+            flags = (bounce & FL_BOUNCE_MASK) | (last_spec ? FL_SPECULAR : 0u) | (state << FL_STATE_SHIFT) |
+                    (first_hit ? FL_FIRST_HIT : 0u) | ((step << FL_STEP_SHIFT) & FL_STEP_MASK);
+            P.rad[p] = make_float4(L.x, L.y, L.z, ra4.w);
+            P.c_sun[p] = make_float4(c_sun.x, c_sun.y, c_sun.z, 0.0f);
+            P.c_sky[p] = make_float4(c_sky.x, c_sky.y, c_sky.z, 0.0f);
+            P.c_post[p] = make_float4(c_post.x, c_post.y, c_post.z, 0.0f);
+            if (push_sun || push_sky) {
+                P.sh_o[p] = make_float4(sh_o.x, sh_o.y, sh_o.z, 0.0f);
+                P.sh_d[p] = make_float4(sh_d.x, sh_d.y, sh_d.z, 0.0f);
+            }
+            if (alive) {
+                P.ray_o[p] = make_float4(ro.x, ro.y, ro.z, ray_tmax);
+                P.ray_d[p] = make_float4(rd.x, rd.y, rd.z, last_pdf);
+                P.thr[p] = make_float4(T.x, T.y, T.z, __uint_as_float(flags));
+                P.rng[p] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+            }
+        }
+        // wave64 ballot/prefix compaction into the three queues
+        queue_push(q_shadow, &ctr->n_shadow, active && push_sun, p * 2u);
+        queue_push(q_shadow, &ctr->n_shadow, active && push_sky, p * 2u + 1u);
+        queue_push(q_next, &ctr_next->n_active, active && alive, p);
+        queue_push(q_final, &ctr->n_final, active && !alive, p);
+    }
+    if (CNT) {
+        wave_add(&dc->v[C_HITDATA], sc.hitdata);
+        wave_add(&dc->v[C_MATERIAL], sc.material);
+        wave_add(&dc->v[C_TEXTURE], sc.texture);
+        wave_add(&dc->v[C_CDF_PROBES], sc.cdf_probes);
+        wave_add(&dc->v[C_SKY_PDF], sc.sky_pdf);
+        wave_add(&dc->v[C_SKY_TEXEL], sc.sky_texel);
+        wave_add(&dc->v[C_SSS_STEPS], sc.sss_steps);
+    }
+}
+
+// ---- finalize: finished paths -> clamp_radiance -> framebuffer ------------------------
+__global__ void k_finalize(PathArrays P, const uint32_t* q_final, const IterCtr* ctr, Target tg, DevCounters* dc, uint32_t counting) {
+    const uint32_t n = ctr->n_final;
+    uint32_t written = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = q_final[i];
+        const float4 ra4 = P.rad[p];
+        V3 L = v3(ra4.x, ra4.y, ra4.z);
+        { const float4 a = P.c_sun[p], b = P.c_sky[p], c = P.c_post[p];
+          L = L + v3(a.x, a.y, a.z); L = L + v3(b.x, b.y, b.z); L = L + v3(c.x, c.y, c.z); }
+        const V3 c = clamp_radiance(L);     // pathtracer.rs:325
+        const uint32_t pixel = __float_as_uint(ra4.w);
+        const size_t o = (size_t)(tg.by_slot ? p : pixel) * 3;
+        if (tg.out_rgb) { tg.out_rgb[o] = c.x; tg.out_rgb[o + 1] = c.y; tg.out_rgb[o + 2] = c.z; }
+        if (tg.out_albedo) {
+            const float4 a = P.aov_a[p], nn = P.aov_n[p];
+            tg.out_albedo[o] = a.x; tg.out_albedo[o + 1] = a.y; tg.out_albedo[o + 2] = a.z;
+            tg.out_normal[o] = nn.x; tg.out_normal[o + 1] = nn.y; tg.out_normal[o + 2] = nn.z;
+        }
+        if (tg.sum) {
+            // Framebuffer::accumulate / AdaptiveFramebuffer::add_sample (framebuffer.rs:44-50, 110-125)
+            const size_t f = (size_t)pixel * 3;
+            tg.sum[f] += c.x; tg.sum[f + 1] += c.y; tg.sum[f + 2] += c.z;
+            if (tg.sum_sq) { tg.sum_sq[f] += c.x * c.x; tg.sum_sq[f + 1] += c.y * c.y; tg.sum_sq[f + 2] += c.z * c.z; }
+            tg.counts[pixel] += 1u;
+        }
+        written++;
+    }
+    if (counting) wave_add(&dc->v[C_PIXEL_SAMPLES], written);
+}
+
+// ---- UnshadedRenderer (renderer/unshaded.rs:7-23) after one extend ---------------------
+__global__ void k_unshaded(SceneDev S, PathArrays P, uint32_t n, float* out_rgb) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float4 rd4 = P.ray_d[p], hi4 = P.hit[p], ra4 = P.rad[p];
+    const V3 rd = v3(rd4.x, rd4.y, rd4.z);
+    const uint32_t inst = __float_as_uint(hi4.w);
+    ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
+    V3 c;
+    if (inst != PTX_MISS) {
+        const HitData hit = compute_hit_data(S, inst, P.hit_tri[p], hi4.x, hi4.y, hi4.z);
+        const PtxMaterial& m = S.materials[hit.material_id];
+        const V3 bcf = v3(m.base_color_factor[0], m.base_color_factor[1], m.base_color_factor[2]);
+        const V3 base = m.base_color_texture >= 0 ? texture_sample(S.textures[m.base_color_texture], S.texels, hit.uvx, hit.uvy, sc.texture) * bcf : bcf;
+        const float n_dot_l = f_max(dot(hit.normal, -rd), 0.0f);
+        c = base * (0.2f + 0.8f * n_dot_l);
+    } else {
+        c = sky_sample(S, rd, sc) * 0.5f;
+    }
+    const size_t o = (size_t)__float_as_uint(ra4.w) * 3;
+    out_rgb[o] = c.x; out_rgb[o + 1] = c.y; out_rgb[o + 2] = c.z;
+}
+
+// ---- adaptive: get_noisy_pixels (framebuffer.rs:181-214) ------------------------------
+__global__ void k_noise_keys(const uint32_t* owned, uint32_t n, const float* sum, const float* sum_sq, const uint32_t* counts,
+                             uint32_t min_samples, float threshold, uint32_t* keys, uint32_t* n_noisy) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        bool noisy = false;
+        if (i < n) {
+            const uint32_t pixel = owned[i];
+            const uint32_t count = counts[pixel];
+            float err;
+            if (count < min_samples) { err = PT_INF; noisy = true; }
+            else {
+                const float nf = (float)count;
+                const size_t f = (size_t)pixel * 3;
+                const V3 mean = v3(sum[f], sum[f + 1], sum[f + 2]) / nf;
+                const V3 mean_sq = v3(sum_sq[f], sum_sq[f + 1], sum_sq[f + 2]) / nf;
+                const V3 variance = mean_sq - mean * mean;
+                const float var_scalar = (f_max(variance.x, 0.0f) + f_max(variance.y, 0.0f) + f_max(variance.z, 0.0f)) / 3.0f;
+                err = sqrtf(var_scalar / nf);
+                noisy = err > threshold;
+            }
+            // key 0 = not selected; selected keys keep the f32 order of err (err >= 0), +1 so that err == 0 stays selected
+            keys[i] = noisy ? (__float_as_uint(err) + 1u) : 0u;
+        }
+        const unsigned long long m = __ballot(noisy);
+        if ((threadIdx.x & 63u) == 0u && m) atomicAdd(n_noisy, (uint32_t)__popcll(m));
+    }
+}
+__global__ void k_compact_noisy(const uint32_t* owned, const uint32_t* keys, uint32_t n, uint32_t* out, uint32_t* out_count) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        const bool sel = i < n && keys[i] != 0u;
+        queue_push(out, out_count, sel, sel ? owned[i] : 0u);
+    }
+}
+__global__ void k_iota(uint32_t* a, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
+__global__ void k_gather(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* dst) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[idx[i]]; }
+
+__global__ void k_fb_stats(const uint32_t* owned, uint32_t n, const uint32_t* counts, uint32_t* out_min, uint32_t* out_max, unsigned long long* out_total) {
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+    unsigned long long tot = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t c = counts[owned[i]];
+        mn = c < mn ? c : mn; mx = c > mx ? c : mx; tot += c;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        tot += __shfl_xor(tot, off);
+    }
+    if ((threadIdx.x & 63u) == 0u) { atomicMin(out_min, mn); atomicMax(out_max, mx); atomicAdd(out_total, tot); }
+}
+__global__ void k_mean(const float* sum, const uint32_t* counts, uint32_t n_pixels, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const uint32_t c = counts[i];
+    const size_t f = (size_t)i * 3;
+    if (c == 0u) { out[f] = 0.0f; out[f + 1] = 0.0f; out[f + 2] = 0.0f; }
+    else { const float cf = (float)c; out[f] = sum[f] / cf; out[f + 1] = sum[f + 1] / cf; out[f + 2] = sum[f + 2] / cf; }
+}
+
+}  // namespace
+
+// ================================================================ host side =====
+struct PtxContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    bool has_scene = false, has_camera = false;
+    SceneDev S{};
+    std::vector<void*> scene_allocs;
+    CameraDev cam{};
+    uint32_t rank = 0, world = 1;
+
+    // path state
+    uint64_t capacity = 0;
+    PathArrays P{};
+    std::vector<void*> path_allocs;
+    uint32_t *q[2] = {nullptr, nullptr}, *q_shadow = nullptr, *q_final = nullptr;
+    IterCtr* ctrs = nullptr;
+    uint2* ovf = nullptr;
+    uint32_t* d_err = nullptr;
+    DevCounters* d_counters = nullptr;
+    uint32_t* h_pinned = nullptr;    // 64 u32 of pinned readback scratch
+
+    // owned-pixel work list (tile order)
+    uint32_t wl_w = 0, wl_h = 0, wl_rank = 0, wl_world = 0, wl_n = 0;
+    uint32_t* wl_pixel = nullptr;
+
+    // staging
+    float* img = nullptr;  uint64_t img_cap = 0;      // 3 images of w*h*3
+    uint32_t* list_a = nullptr; uint32_t* list_b = nullptr; uint32_t* list_c = nullptr; uint32_t* list_d = nullptr; uint64_t list_cap = 0;
+    void* cub_tmp = nullptr; size_t cub_tmp_bytes = 0;
+
+    // framebuffer
+    uint32_t fb_w = 0, fb_h = 0; bool fb_adaptive = false;
+    float *fb_sum = nullptr, *fb_sum_sq = nullptr; uint32_t* fb_counts = nullptr;
+
+    bool counting = false, profiling = false;
+    struct Ev { hipEvent_t a, b; int cls; };
+    std::vector<Ev> events;
+    PtxTimings timings{};
+};
+
+static std::string g_last_error;
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            char buf_[512];                                                                                   \
+            snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            if (ctx) ctx->err = buf_; else g_last_error = buf_;                                               \
+            return PTX_ERR_HIP;                                                                               \
+        }                                                                                                     \
+    } while (0)
+
+static int32_t fail(PtxContext* ctx, int32_t code, const char* msg) {
+    if (ctx) ctx->err = msg; else g_last_error = msg;
+    return code;
+}
+
+template <class T>
+static hipError_t dev_alloc(std::vector<void*>& pool, T** out, size_t count) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) { pool.push_back(p); *out = static_cast<T*>(p); }
+    return e;
+}
+template <class T>
+static hipError_t dev_upload(std::vector<void*>& pool, const T** out, const std::vector<T>& v) {
+    T* p = nullptr;
+    hipError_t e = dev_alloc(pool, &p, v.size());
+    if (e != hipSuccess) return e;
+    if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    *out = p;
+    return e;
+}
+static void free_pool(std::vector<void*>& pool) {
+    for (void* p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+// ---- Bvh8Node[] (256 B, 8 slots) -> NodeRec[] (128 B, <= 4 children, chained) ------------
+static bool repack_bvh(const PtxBvh8& bvh, uint32_t n_prims_expected_max, std::vector<NodeRec>& out, uint32_t* n_records) {
+    const size_t first = out.size();
+    std::vector<uint32_t> rec_index(bvh.n_nodes);
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < bvh.n_nodes; ++i) {
+        const int nv = __builtin_popcount(bvh.nodes[i].valid_mask);
+        rec_index[i] = total;
+        total += nv > 4 ? 2u : 1u;
+    }
+    out.resize(first + total);
+    for (uint32_t i = 0; i < bvh.n_nodes; ++i) {
+        const PtxBvh8Node& n = bvh.nodes[i];
+        const int nv = __builtin_popcount(n.valid_mask);
+        int slots[8], ns = 0;
+        for (int s = 0; s < 8; ++s) if (n.valid_mask & (1u << s)) slots[ns++] = s;
+        const int nrec = nv > 4 ? 2 : 1;
+        for (int r = 0; r < nrec; ++r) {
+            NodeRec& rec = out[first + rec_index[i] + r];
+            std::memset(&rec, 0, sizeof(rec));
+            const int begin = r * 4, end = std::min(ns, begin + 4);
+            for (int k = begin; k < end; ++k) {
+                const int s = slots[k];
+                uint32_t word = n.children[s];
+                if (word & LEAF_FLAG) {
+                    const uint32_t start = word & PRIM_START_MASK, count = ((word >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
+                    if ((uint64_t)start + count > bvh.n_primitive_indices) return false;
+                } else {
+                    if (word >= bvh.n_nodes) return false;
+                    word = rec_index[word];
+                }
+                float wf;
+                std::memcpy(&wf, &word, 4);
+                rec.c[2 * (k - begin)] = make_float4(n.min_x[s], n.min_y[s], n.min_z[s], n.max_x[s]);
+                rec.c[2 * (k - begin) + 1] = make_float4(n.max_y[s], n.max_z[s], wf, 0.0f);
+            }
+            const uint32_t meta = (uint32_t)(end - begin) | ((r + 1 < nrec) ? 8u : 0u) | ((uint32_t)nv << 8);
+            float mf;
+            std::memcpy(&mf, &meta, 4);
+            rec.c[1].w = mf;
+        }
+    }
+    (void)n_prims_expected_max;
+    *n_records = total;
+    return true;
+}
+
+static void pack_cols(const float* m, float4* dst) {
+    // columns x,y,z,w (xyz of each) -> 3 float4
+    dst[0] = make_float4(m[0], m[1], m[2], m[4]);
+    dst[1] = make_float4(m[5], m[6], m[8], m[9]);
+    dst[2] = make_float4(m[10], m[12], m[13], m[14]);
+}
+
+static int32_t ensure_lists(PtxContext* ctx, uint64_t n) {
+    if (n <= ctx->list_cap) return PTX_OK;
+    for (uint32_t** p : {&ctx->list_a, &ctx->list_b, &ctx->list_c, &ctx->list_d}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    HIPCHK(hipMalloc((void**)&ctx->list_a, n * 3 * 4));
+    HIPCHK(hipMalloc((void**)&ctx->list_b, n * 4));
+    HIPCHK(hipMalloc((void**)&ctx->list_c, n * 4));
+    HIPCHK(hipMalloc((void**)&ctx->list_d, n * 4));
+    ctx->list_cap = n;
+    return PTX_OK;
+}
+
+static int32_t ensure_capacity(PtxContext* ctx, uint64_t n) {
+    if (n <= ctx->capacity) return PTX_OK;
+    free_pool(ctx->path_allocs);
+    ctx->capacity = 0;
+    PathArrays& P = ctx->P;
+    auto& pool = ctx->path_allocs;
+    HIPCHK(dev_alloc(pool, &P.ray_o, n)); HIPCHK(dev_alloc(pool, &P.ray_d, n)); HIPCHK(dev_alloc(pool, &P.thr, n));
+    HIPCHK(dev_alloc(pool, &P.rad, n)); HIPCHK(dev_alloc(pool, &P.rng, n)); HIPCHK(dev_alloc(pool, &P.hit, n));
+    HIPCHK(dev_alloc(pool, &P.hit_tri, n)); HIPCHK(dev_alloc(pool, &P.sh_o, n)); HIPCHK(dev_alloc(pool, &P.sh_d, n));
+    HIPCHK(dev_alloc(pool, &P.c_sun, n)); HIPCHK(dev_alloc(pool, &P.c_sky, n)); HIPCHK(dev_alloc(pool, &P.c_post, n));
+    HIPCHK(dev_alloc(pool, &P.w_t, n)); HIPCHK(dev_alloc(pool, &P.w_b, n)); HIPCHK(dev_alloc(pool, &P.aov_a, n));
+    HIPCHK(dev_alloc(pool, &P.aov_n, n)); HIPCHK(dev_alloc(pool, &P.sample, n));
+    HIPCHK(dev_alloc(pool, &ctx->q[0], n)); HIPCHK(dev_alloc(pool, &ctx->q[1], n));
+    HIPCHK(dev_alloc(pool, &ctx->q_shadow, 2 * n)); HIPCHK(dev_alloc(pool, &ctx->q_final, n));
+    ctx->capacity = n;
+    return PTX_OK;
+}
+
+static int32_t ensure_images(PtxContext* ctx, uint64_t n_pixels) {
+    if (n_pixels <= ctx->img_cap) return PTX_OK;
+    if (ctx->img) (void)hipFree(ctx->img);
+    ctx->img = nullptr; ctx->img_cap = 0;
+    HIPCHK(hipMalloc((void**)&ctx->img, n_pixels * 9 * sizeof(float)));
+    ctx->img_cap = n_pixels;
+    return PTX_OK;
+}
+
+// owned pixels in 8x8-tile order: one wave of primary rays == one tile
+static int32_t ensure_worklist(PtxContext* ctx, uint32_t w, uint32_t h) {
+    if (ctx->wl_pixel && ctx->wl_w == w && ctx->wl_h == h && ctx->wl_rank == ctx->rank && ctx->wl_world == ctx->world) return PTX_OK;
+    std::vector<uint32_t> list;
+    list.reserve((size_t)w * h / ctx->world + 64);
+    const uint32_t tx_n = (w + 7) / 8, ty_n = (h + 7) / 8;
+    for (uint32_t ty = 0; ty < ty_n; ++ty)
+        for (uint32_t tx = 0; tx < tx_n; ++tx) {
+            const uint32_t t = ty * tx_n + tx;
+            if (t % ctx->world != ctx->rank) continue;
+            for (uint32_t ly = 0; ly < 8; ++ly)
+                for (uint32_t lx = 0; lx < 8; ++lx) {
+                    const uint32_t x = tx * 8 + lx, y = ty * 8 + ly;
+                    if (x < w && y < h) list.push_back(y * w + x);
+                }
+        }
+    if (ctx->wl_pixel) (void)hipFree(ctx->wl_pixel);
+    ctx->wl_pixel = nullptr;
+    HIPCHK(hipMalloc((void**)&ctx->wl_pixel, std::max<size_t>(list.size(), 1) * 4));
+    if (!list.empty()) HIPCHK(hipMemcpy(ctx->wl_pixel, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+    ctx->wl_w = w; ctx->wl_h = h; ctx->wl_rank = ctx->rank; ctx->wl_world = ctx->world; ctx->wl_n = (uint32_t)list.size();
+    return PTX_OK;
+}
+
+enum { CLS_RAYGEN = 0, CLS_EXTEND, CLS_SHADE, CLS_SHADOW, CLS_ACCUM, CLS_OTHER };
+struct ScopedEvent {
+    PtxContext* ctx; int idx = -1;
+    ScopedEvent(PtxContext* c, int cls) : ctx(c) {
+        if (!c->profiling) return;
+        PtxContext::Ev e; e.cls = cls;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+        (void)hipEventRecord(e.a, c->stream);
+        c->events.push_back(e); idx = (int)c->events.size() - 1;
+    }
+    ~ScopedEvent() { if (idx >= 0) (void)hipEventRecord(ctx->events[idx].b, ctx->stream); }
+};
+static void drain_events(PtxContext* ctx) {
+    if (ctx->events.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& e : ctx->events) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            switch (e.cls) {
+                case CLS_RAYGEN: ctx->timings.raygen_ms += ms; break;
+                case CLS_EXTEND: ctx->timings.extend_ms += ms; ctx->timings.extend_launches++; break;
+                case CLS_SHADE: ctx->timings.shade_ms += ms; ctx->timings.shade_launches++; break;
+                case CLS_SHADOW: ctx->timings.shadow_ms += ms; ctx->timings.shadow_launches++; break;
+                case CLS_ACCUM: ctx->timings.accumulate_ms += ms; break;
+                default: ctx->timings.other_ms += ms; break;
+            }
+        }
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    ctx->events.clear();
+}
+
+static int32_t check_device_error(PtxContext* ctx) {
+    // d_err is read back through pinned memory on the library stream
+    HIPCHK(hipMemcpyAsync(ctx->h_pinned, ctx->d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pinned[0] != 0) {
+        HIPCHK(hipMemsetAsync(ctx->d_err, 0, 4, ctx->stream));
+        return fail(ctx, PTX_ERR_STACK_OVERFLOW, "traversal stack exceeded 64 entries on one BVH level (the reference would panic)");
+    }
+    return PTX_OK;
+}
+
+// Trace n path slots that k_raygen is about to initialise from (wl_pixel, wl_sample | fb counts | uniform).
+static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32_t* wl_sample, const uint32_t* per_pixel_counts,
+                         uint32_t uniform_sample, uint32_t n, uint32_t w, uint32_t h, uint32_t max_bounces, const Target& tg, bool aov) {
+    if (n == 0) return PTX_OK;
+    int32_t st = ensure_capacity(ctx, n);
+    if (st != PTX_OK) return st;
+    const bool sss = ctx->S.has_sss != 0;
+    const uint32_t iter_cap = sss ? MAX_ITERS - 1 : std::min<uint32_t>(max_bounces, MAX_ITERS - 1);
+    HIPCHK(hipMemsetAsync(ctx->ctrs, 0, sizeof(IterCtr) * (size_t)(sss ? MAX_ITERS : iter_cap + 1), ctx->stream));
+    {
+        ScopedEvent ev(ctx, CLS_RAYGEN);
+        hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->cam, ctx->P, wl_pixel, wl_sample,
+                           per_pixel_counts, uniform_sample, n, w, h, ctx->q[0], ctx->ctrs, aov ? 1u : 0u, (PtxRay*)nullptr);
+    }
+    const int trace_grid = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
+    const int shade_grid = (int)std::min<uint64_t>(256 * 8, (n + SHADE_BLOCK - 1) / SHADE_BLOCK);
+    for (uint32_t it = 0; it < iter_cap; ++it) {
+        uint32_t* qa = ctx->q[it & 1];
+        uint32_t* qb = ctx->q[(it + 1) & 1];
+        IterCtr* c = ctx->ctrs + it;
+        {
+            ScopedEvent ev(ctx, CLS_EXTEND);
+            if (ctx->counting) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+        }
+        {
+            ScopedEvent ev(ctx, CLS_SHADE);
+            if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(SHADE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
+            else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(SHADE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
+        }
+        {
+            ScopedEvent ev(ctx, CLS_SHADOW);
+            const int sg = (int)std::min<uint64_t>(TRACE_GRID, (2ull * n + TRACE_BLOCK - 1) / TRACE_BLOCK);
+            if (ctx->counting) hipLaunchKernelGGL(k_shadow<true>, dim3(sg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q_shadow, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(sg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q_shadow, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+        }
+        {
+            ScopedEvent ev(ctx, CLS_ACCUM);
+            hipLaunchKernelGGL(k_finalize, dim3(shade_grid), dim3(SHADE_BLOCK), 0, ctx->stream, ctx->P, ctx->q_final, c, tg, ctx->d_counters, ctx->counting ? 1u : 0u);
+        }
+        if (sss && it + 1 >= max_bounces) {
+            // subsurface walks make the iteration count data dependent: poll the live count
+            HIPCHK(hipMemcpyAsync(ctx->h_pinned + 1, &ctx->ctrs[it + 1].n_active, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (ctx->h_pinned[1] == 0) break;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    if (ctx->counting) {
+        // primary rays are counted on the host side of the launch: one per slot
+        ctx->timings.other_ms += 0.0;
+    }
+    return PTX_OK;
+}
+
+#define REQUIRE_CTX() do { if (!ctx) return fail(nullptr, PTX_ERR_INVALID, "null context"); (void)hipSetDevice(ctx->device); } while (0)
+#define REQUIRE_SCENE() do { REQUIRE_CTX(); if (!ctx->has_scene) return fail(ctx, PTX_ERR_NO_SCENE, "no scene uploaded"); } while (0)
+#define REQUIRE_CAMERA() do { REQUIRE_SCENE(); if (!ctx->has_camera) return fail(ctx, PTX_ERR_INVALID, "no camera set"); } while (0)
+
+static void add_primary_count(PtxContext* ctx, uint64_t n) {
+    if (!ctx->counting) return;
+    unsigned long long v = n;
+    // host-side bump of one device counter (rare, tiny)
+    unsigned long long cur = 0;
+    (void)hipMemcpyAsync(&cur, &ctx->d_counters->v[C_PRIMARY], 8, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    cur += v;
+    (void)hipMemcpyAsync(&ctx->d_counters->v[C_PRIMARY], &cur, 8, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+}
+
+extern "C" {
+
+const char* ptx_last_error(const PtxContext* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
+    PtxContext* ctx = nullptr;
+    if (!out_ctx) return fail(nullptr, PTX_ERR_INVALID, "out_ctx is null");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(nullptr, PTX_ERR_NO_DEVICE, "no HIP device visible");
+    if (device_index < 0 || device_index >= count) return fail(nullptr, PTX_ERR_NO_DEVICE, "device index out of range");
+    HIPCHK(hipSetDevice(device_index));
+    PtxContext* c = new PtxContext();
+    c->device = device_index;
+    ctx = c;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * MAX_ITERS));
+    HIPCHK(hipMalloc((void**)&c->ovf, sizeof(uint2) * (size_t)TRACE_GRID * TRACE_BLOCK * OVF_STACK));
+    HIPCHK(hipMalloc((void**)&c->d_err, 4));
+    HIPCHK(hipMemset(c->d_err, 0, 4));
+    HIPCHK(hipMalloc((void**)&c->d_counters, sizeof(DevCounters)));
+    HIPCHK(hipMemset(c->d_counters, 0, sizeof(DevCounters)));
+    HIPCHK(hipHostMalloc((void**)&c->h_pinned, 64 * 4, hipHostMallocDefault));
+    *out_ctx = c;
+    return PTX_OK;
+}
+
+int32_t ptx_destroy(PtxContext* ctx) {
+    if (!ctx) return PTX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_events(ctx);
+    free_pool(ctx->scene_allocs);
+    free_pool(ctx->path_allocs);
+    for (void* p : {(void*)ctx->ctrs, (void*)ctx->ovf, (void*)ctx->d_err, (void*)ctx->d_counters, (void*)ctx->wl_pixel, (void*)ctx->img,
+                    (void*)ctx->list_a, (void*)ctx->list_b, (void*)ctx->list_c, (void*)ctx->list_d, (void*)ctx->cub_tmp,
+                    (void*)ctx->fb_sum, (void*)ctx->fb_sum_sq, (void*)ctx->fb_counts})
+        if (p) (void)hipFree(p);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PTX_OK;
+}
+
+int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
+    REQUIRE_CTX();
+    if (!sc || sc->abi_version != PTX_ABI_VERSION) return fail(ctx, PTX_ERR_INVALID, "scene descriptor missing or ABI version mismatch");
+    if (sc->n_instances && (!sc->instances || !sc->tlas.nodes)) return fail(ctx, PTX_ERR_INVALID, "instances without a TLAS");
+    if (!sc->n_materials || !sc->materials) return fail(ctx, PTX_ERR_INVALID, "scene needs at least one material");
+    if (!sc->blue_noise_pixel.samples || !sc->blue_noise_lens.samples || sc->blue_noise_pixel.size != sc->blue_noise_lens.size || !sc->blue_noise_pixel.size)
+        return fail(ctx, PTX_ERR_INVALID, "blue-noise tables missing");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_pool(ctx->scene_allocs);
+    ctx->has_scene = false;
+
+    std::vector<NodeRec> nodes;
+    std::vector<TriRec> tris;
+    std::vector<MeshRec> meshes(sc->n_meshes);
+    std::vector<float> positions, normals, uvs;
+    std::vector<uint32_t> indices;
+    uint32_t nrec = 0;
+    if (sc->n_instances) {
+        if (!repack_bvh(sc->tlas, sc->n_instances, nodes, &nrec)) return fail(ctx, PTX_ERR_INVALID, "TLAS child word out of range");
+        for (uint32_t i = 0; i < sc->tlas.n_primitive_indices; ++i)
+            if (sc->tlas.primitive_indices[i] >= sc->n_instances) return fail(ctx, PTX_ERR_INVALID, "TLAS primitive index out of range");
+    }
+    const uint32_t n_tlas_records = nrec;
+    for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
+        const PtxMesh& m = sc->meshes[mi];
+        if (!m.positions || !m.indices || !m.n_triangles) return fail(ctx, PTX_ERR_INVALID, "mesh without geometry");
+        if (m.material_id >= sc->n_materials) return fail(ctx, PTX_ERR_INVALID, "mesh material id out of range");
+        MeshRec& r = meshes[mi];
+        r.pos_base = (uint32_t)positions.size();
+        positions.insert(positions.end(), m.positions, m.positions + (size_t)m.n_positions * 3);
+        if (m.n_normals) { r.nrm_base = (uint32_t)normals.size(); normals.insert(normals.end(), m.normals, m.normals + (size_t)m.n_normals * 3); } else r.nrm_base = 0xFFFFFFFFu;
+        if (m.n_uvs) { r.uv_base = (uint32_t)uvs.size(); uvs.insert(uvs.end(), m.uvs, m.uvs + (size_t)m.n_uvs * 2); } else r.uv_base = 0xFFFFFFFFu;
+        r.idx_base = (uint32_t)indices.size();
+        for (size_t k = 0; k < (size_t)m.n_triangles * 3; ++k) {
+            if (m.indices[k] >= m.n_positions || (m.n_normals && m.indices[k] >= m.n_normals) || (m.n_uvs && m.indices[k] >= m.n_uvs))
+                return fail(ctx, PTX_ERR_INVALID, "vertex index out of range");
+            indices.push_back(m.indices[k]);
+        }
+        r.material_id = m.material_id;
+        r.n_triangles = m.n_triangles;
+        r.node_base = (uint32_t)nodes.size();
+        r.tri_base = (uint32_t)tris.size();
+        if (m.bvh.n_nodes == 0) {   // Bvh8::empty(): traverse_* return None/false
+            NodeRec e; std::memset(&e, 0, sizeof(e)); nodes.push_back(e);
+        } else if (!repack_bvh(m.bvh, m.n_triangles, nodes, &nrec)) return fail(ctx, PTX_ERR_INVALID, "mesh BVH child word out of range");
+        for (uint32_t s = 0; s < m.bvh.n_primitive_indices; ++s) {
+            const uint32_t t = m.bvh.primitive_indices[s];
+            if (t >= m.n_triangles) return fail(ctx, PTX_ERR_INVALID, "mesh BVH primitive index out of range");
+            const uint32_t* tri = &m.indices[3 * (size_t)t];
+            const float* p0 = &m.positions[3 * (size_t)tri[0]]; const float* p1 = &m.positions[3 * (size_t)tri[1]]; const float* p2 = &m.positions[3 * (size_t)tri[2]];
+            TriRec tr;
+            float tf; std::memcpy(&tf, &t, 4);
+            tr.a = make_float4(p0[0], p0[1], p0[2], p1[0] - p0[0]);
+            tr.b = make_float4(p1[1] - p0[1], p1[2] - p0[2], p2[0] - p0[0], p2[1] - p0[1]);
+            tr.c = make_float4(p2[2] - p0[2], tf, 0.0f, 0.0f);
+            tris.push_back(tr);
+        }
+    }
+    std::vector<InstRec> inst(sc->n_instances);
+    std::vector<InstShade> inst_shade(sc->n_instances);
+    for (uint32_t i = 0; i < sc->n_instances; ++i) {
+        const PtxInstance& in = sc->instances[i];
+        if (in.blas_index >= sc->n_meshes) return fail(ctx, PTX_ERR_INVALID, "instance blas index out of range");
+        const PtxMesh& m = sc->meshes[in.blas_index];
+        InstRec& r = inst[i];
+        pack_cols(in.inverse_transform, &r.m[0]);
+        r.m[3] = make_float4(m.bounds_min[0], m.bounds_min[1], m.bounds_min[2], m.bounds_max[0]);
+        float nb, tb;
+        std::memcpy(&nb, &meshes[in.blas_index].node_base, 4);
+        std::memcpy(&tb, &meshes[in.blas_index].tri_base, 4);
+        r.m[4] = make_float4(m.bounds_max[1], m.bounds_max[2], nb, tb);
+        pack_cols(in.transform, &r.m[5]);
+        const float* nm = in.normal_matrix;
+        InstShade& s = inst_shade[i];
+        s.n[0] = nm[0]; s.n[1] = nm[1]; s.n[2] = nm[2]; s.n[3] = nm[4]; s.n[4] = nm[5]; s.n[5] = nm[6]; s.n[6] = nm[8]; s.n[7] = nm[9]; s.n[8] = nm[10];
+        s.mesh_id = in.blas_index; s.pad[0] = s.pad[1] = 0;
+    }
+    std::vector<PtxMaterial> materials(sc->materials, sc->materials + sc->n_materials);
+    bool has_sss = false;
+    for (auto& m : materials) {
+        for (int32_t t : {m.base_color_texture, m.metallic_roughness_texture, m.normal_texture, m.emissive_texture})
+            if (t >= (int32_t)sc->n_textures) return fail(ctx, PTX_ERR_INVALID, "material texture id out of range");
+        if (m.subsurface > 0.0f) has_sss = true;
+    }
+    std::vector<TexRec> textures(sc->n_textures);
+    std::vector<float> texels;
+    auto add_tex = [&](const PtxTexture& t) {
+        TexRec r;
+        r.width = t.width; r.height = t.height; r.pad = 0;
+        r.solid[0] = t.solid[0]; r.solid[1] = t.solid[1]; r.solid[2] = t.solid[2];
+        if (t.texels && t.width && t.height) { r.offset = texels.size(); texels.insert(texels.end(), t.texels, t.texels + (size_t)t.width * t.height * 3); }
+        else r.offset = ~0ull;
+        return r;
+    };
+    for (uint32_t i = 0; i < sc->n_textures; ++i) textures[i] = add_tex(sc->textures[i]);
+    SceneDev S{};
+    S.sky_tex = add_tex(sc->sky.texture);
+    S.sky_w = sc->sky.width; S.sky_h = sc->sky.height;
+    S.sky_total_weight = sc->sky.total_weight; S.sky_rotation = sc->sky.rotation;
+    if (!sc->sky.marginal_cdf || !sc->sky.conditional_cdfs || !S.sky_w || !S.sky_h) return fail(ctx, PTX_ERR_INVALID, "sky CDFs missing");
+    std::vector<float> marginal(sc->sky.marginal_cdf, sc->sky.marginal_cdf + S.sky_h + 1);
+    std::vector<float> conditional(sc->sky.conditional_cdfs, sc->sky.conditional_cdfs + (size_t)S.sky_h * (S.sky_w + 1));
+    std::vector<uint32_t> tlas_prims(sc->tlas.primitive_indices, sc->tlas.primitive_indices + (sc->n_instances ? sc->tlas.n_primitive_indices : 0));
+    const size_t bn = (size_t)sc->blue_noise_pixel.size * sc->blue_noise_pixel.size * 2;
+    std::vector<float> bn_pixel(sc->blue_noise_pixel.samples, sc->blue_noise_pixel.samples + bn);
+    std::vector<float> bn_lens(sc->blue_noise_lens.samples, sc->blue_noise_lens.samples + bn);
+
+    auto& pool = ctx->scene_allocs;
+    HIPCHK(dev_upload(pool, &S.nodes, nodes)); HIPCHK(dev_upload(pool, &S.tlas_prims, tlas_prims)); HIPCHK(dev_upload(pool, &S.tris, tris));
+    HIPCHK(dev_upload(pool, &S.inst, inst)); HIPCHK(dev_upload(pool, &S.inst_shade, inst_shade)); HIPCHK(dev_upload(pool, &S.meshes, meshes));
+    HIPCHK(dev_upload(pool, &S.positions, positions)); HIPCHK(dev_upload(pool, &S.normals, normals)); HIPCHK(dev_upload(pool, &S.uvs, uvs));
+    HIPCHK(dev_upload(pool, &S.indices, indices)); HIPCHK(dev_upload(pool, &S.materials, materials)); HIPCHK(dev_upload(pool, &S.textures, textures));
+    HIPCHK(dev_upload(pool, &S.texels, texels)); HIPCHK(dev_upload(pool, &S.sky_marginal, marginal)); HIPCHK(dev_upload(pool, &S.sky_conditional, conditional));
+    HIPCHK(dev_upload(pool, &S.bn_pixel, bn_pixel)); HIPCHK(dev_upload(pool, &S.bn_lens, bn_lens));
+    S.bn_size = sc->blue_noise_pixel.size;
+    S.sun_enabled = sc->sun.enabled;
+    for (int k = 0; k < 3; ++k) { S.sun_dir[k] = sc->sun.direction[k]; S.sun_color[k] = sc->sun.color[k]; }
+    S.sun_cos_angle = sc->sun.cos_angle; S.sun_pdf = sc->sun.pdf;
+    S.n_tlas_nodes = sc->n_instances ? n_tlas_records : 0;
+    S.has_sss = has_sss ? 1u : 0u;
+    ctx->S = S;
+    ctx->has_scene = true;
+    return PTX_OK;
+}
+
+int32_t ptx_set_camera(PtxContext* ctx, const PtxCamera* cam) {
+    REQUIRE_CTX();
+    if (!cam) return fail(ctx, PTX_ERR_INVALID, "camera is null");
+    std::memcpy(ctx->cam.inv_vp, cam->inv_vp_matrix, sizeof(float) * 16);
+    ctx->cam.aperture = cam->aperture; ctx->cam.focus_distance = cam->focus_distance;
+    for (int k = 0; k < 3; ++k) { ctx->cam.right[k] = cam->right[k]; ctx->cam.up[k] = cam->up[k]; }
+    ctx->has_camera = true;
+    return PTX_OK;
+}
+
+int32_t ptx_set_partition(PtxContext* ctx, uint32_t rank, uint32_t world) {
+    REQUIRE_CTX();
+    if (world == 0 || rank >= world) return fail(ctx, PTX_ERR_INVALID, "partition needs rank < world");
+    ctx->rank = rank; ctx->world = world;
+    return PTX_OK;
+}
+
+int32_t ptx_sync(PtxContext* ctx) {
+    REQUIRE_CTX();
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PTX_OK;
+}
+
+static int32_t render_to_images(PtxContext* ctx, uint32_t w, uint32_t h, uint32_t sample_index, uint32_t max_bounces, float* out_rgb,
+                                float* out_albedo, float* out_normal, int mode /*0 pt, 1 aov, 2 unshaded*/) {
+    if (!w || !h || !out_rgb || (uint64_t)w * h > 0x7FFFFFFFull) return fail(ctx, PTX_ERR_INVALID, "bad image size or null output");
+    int32_t st = ensure_worklist(ctx, w, h);
+    if (st != PTX_OK) return st;
+    const uint64_t npx = (uint64_t)w * h;
+    st = ensure_images(ctx, npx);
+    if (st != PTX_OK) return st;
+    float* d_rgb = ctx->img; float* d_alb = ctx->img + npx * 3; float* d_nrm = ctx->img + npx * 6;
+    HIPCHK(hipMemsetAsync(ctx->img, 0, npx * 9 * sizeof(float), ctx->stream));   // pixels another rank owns stay 0
+    const uint32_t n = ctx->wl_n;
+    if (mode == 2) {
+        st = ensure_capacity(ctx, n);
+        if (st != PTX_OK) return st;
+        if (n) {
+            HIPCHK(hipMemsetAsync(ctx->ctrs, 0, sizeof(IterCtr) * 2, ctx->stream));
+            hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->cam, ctx->P, ctx->wl_pixel, (const uint32_t*)nullptr,
+                               (const uint32_t*)nullptr, sample_index, n, w, h, ctx->q[0], ctx->ctrs, 0u, (PtxRay*)nullptr);
+            const int tg = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
+            hipLaunchKernelGGL(k_extend<false>, dim3(tg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q[0], ctx->ctrs, ctx->ovf, ctx->d_counters, ctx->d_err);
+            hipLaunchKernelGGL(k_unshaded, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->P, n, d_rgb);
+        }
+    } else {
+        Target tg{};
+        tg.out_rgb = d_rgb;
+        if (mode == 1) { tg.out_albedo = d_alb; tg.out_normal = d_nrm; }
+        st = run_paths(ctx, ctx->wl_pixel, nullptr, nullptr, sample_index, n, w, h, max_bounces, tg, mode == 1);
+        if (st != PTX_OK) return st;
+        add_primary_count(ctx, n);
+    }
+    HIPCHK(hipMemcpyAsync(out_rgb, d_rgb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (mode == 1) {
+        HIPCHK(hipMemcpyAsync(out_albedo, d_alb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(out_normal, d_nrm, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return check_device_error(ctx);
+}
+
+int32_t ptx_render_pass(PtxContext* ctx, uint32_t w, uint32_t h, uint32_t sample_index, uint32_t max_bounces, float* out_rgb) {
+    REQUIRE_CAMERA();
+    return render_to_images(ctx, w, h, sample_index, max_bounces, out_rgb, nullptr, nullptr, 0);
+}
+
+int32_t ptx_render_first_pass_aov(PtxContext* ctx, uint32_t w, uint32_t h, uint32_t max_bounces, float* out_rgb, float* out_albedo, float* out_normal) {
+    REQUIRE_CAMERA();
+    if (!out_albedo || !out_normal) return fail(ctx, PTX_ERR_INVALID, "AOV outputs are null");
+    return render_to_images(ctx, w, h, 0, max_bounces, out_rgb, out_albedo, out_normal, 1);
+}
+
+int32_t ptx_render_pass_unshaded(PtxContext* ctx, uint32_t w, uint32_t h, uint32_t sample_index, float* out_rgb) {
+    REQUIRE_CAMERA();
+    return render_to_images(ctx, w, h, sample_index, 0, out_rgb, nullptr, nullptr, 2);
+}
+
+int32_t ptx_render_pixels(PtxContext* ctx, uint32_t w, uint32_t h, const uint32_t* xys, uint64_t n, uint32_t max_bounces, float* out_rgb) {
+    REQUIRE_CAMERA();
+    if (n == 0) return PTX_OK;
+    if (!xys || !out_rgb || !w || !h || n > 0x7FFFFFFFull) return fail(ctx, PTX_ERR_INVALID, "bad work list");
+    std::vector<uint32_t> pix(n), smp(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (xys[3 * i] >= w || xys[3 * i + 1] >= h) return fail(ctx, PTX_ERR_INVALID, "work-list pixel outside the image");
+        pix[i] = xys[3 * i + 1] * w + xys[3 * i];
+        smp[i] = xys[3 * i + 2];
+    }
+    int32_t st = ensure_lists(ctx, n);
+    if (st != PTX_OK) return st;
+    HIPCHK(hipMemcpyAsync(ctx->list_b, pix.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->list_c, smp.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // pix/smp are stack-lifetime host vectors
+    Target tg{};
+    tg.out_rgb = reinterpret_cast<float*>(ctx->list_a);   // n*3 floats, by slot
+    tg.by_slot = 1;
+    st = run_paths(ctx, ctx->list_b, ctx->list_c, nullptr, 0, (uint32_t)n, w, h, max_bounces, tg, false);
+    if (st != PTX_OK) return st;
+    add_primary_count(ctx, n);
+    HIPCHK(hipMemcpyAsync(out_rgb, ctx->list_a, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    return check_device_error(ctx);
+}
+
+// ---- framebuffer -------------------------------------------------------------------------
+int32_t ptx_fb_reset(PtxContext* ctx, uint32_t w, uint32_t h, int32_t adaptive) {
+    REQUIRE_CTX();
+    if (!w || !h || (uint64_t)w * h > 0x7FFFFFFFull) return fail(ctx, PTX_ERR_INVALID, "bad framebuffer size");
+    const uint64_t npx = (uint64_t)w * h;
+    if (ctx->fb_w != w || ctx->fb_h != h || ctx->fb_adaptive != (adaptive != 0) || !ctx->fb_sum) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (void* p : {(void*)ctx->fb_sum, (void*)ctx->fb_sum_sq, (void*)ctx->fb_counts}) if (p) (void)hipFree(p);
+        ctx->fb_sum = ctx->fb_sum_sq = nullptr; ctx->fb_counts = nullptr;
+        HIPCHK(hipMalloc((void**)&ctx->fb_sum, npx * 3 * sizeof(float)));
+        if (adaptive) HIPCHK(hipMalloc((void**)&ctx->fb_sum_sq, npx * 3 * sizeof(float)));
+        HIPCHK(hipMalloc((void**)&ctx->fb_counts, npx * 4));
+        ctx->fb_w = w; ctx->fb_h = h; ctx->fb_adaptive = adaptive != 0;
+    }
+    HIPCHK(hipMemsetAsync(ctx->fb_sum, 0, npx * 3 * sizeof(float), ctx->stream));
+    if (ctx->fb_sum_sq) HIPCHK(hipMemsetAsync(ctx->fb_sum_sq, 0, npx * 3 * sizeof(float), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->fb_counts, 0, npx * 4, ctx->stream));
+    return PTX_OK;
+}
+
+#define REQUIRE_FB() do { REQUIRE_CAMERA(); if (!ctx->fb_sum) return fail(ctx, PTX_ERR_INVALID, "no framebuffer: call ptx_fb_reset"); } while (0)
+
+int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t count, uint32_t max_bounces) {
+    REQUIRE_FB();
+    int32_t st = ensure_worklist(ctx, ctx->fb_w, ctx->fb_h);
+    if (st != PTX_OK) return st;
+    Target tg{};
+    tg.sum = ctx->fb_sum; tg.sum_sq = ctx->fb_sum_sq; tg.counts = ctx->fb_counts;
+    for (uint32_t k = 0; k < count; ++k) {
+        st = run_paths(ctx, ctx->wl_pixel, nullptr, nullptr, first_sample + k, ctx->wl_n, ctx->fb_w, ctx->fb_h, max_bounces, tg, false);
+        if (st != PTX_OK) return st;
+    }
+    add_primary_count(ctx, (uint64_t)ctx->wl_n * count);
+    return PTX_OK;
+}
+
+int32_t ptx_fb_adaptive_pass(PtxContext* ctx, const PtxAdaptiveConfig* cfg, uint32_t max_bounces, uint64_t* out_rendered) {
+    REQUIRE_FB();
+    if (!cfg || !out_rendered) return fail(ctx, PTX_ERR_INVALID, "null argument");
+    if (!ctx->fb_adaptive) return fail(ctx, PTX_ERR_INVALID, "framebuffer was not created adaptive");
+    *out_rendered = 0;
+    int32_t st = ensure_worklist(ctx, ctx->fb_w, ctx->fb_h);
+    if (st != PTX_OK) return st;
+    const uint32_t n = ctx->wl_n;
+    if (n == 0) return PTX_OK;
+    st = ensure_lists(ctx, n);
+    if (st != PTX_OK) return st;
+    uint32_t* keys = ctx->list_b; uint32_t* work = ctx->list_c;
+    uint32_t* d_count = reinterpret_cast<uint32_t*>(&ctx->ctrs[MAX_ITERS - 1]);   // spare counter block
+    HIPCHK(hipMemsetAsync(d_count, 0, sizeof(IterCtr), ctx->stream));
+    const int grid = (int)std::min<uint32_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(k_noise_keys, dim3(grid), dim3(256), 0, ctx->stream, ctx->wl_pixel, n, ctx->fb_sum, ctx->fb_sum_sq, ctx->fb_counts,
+                       cfg->min_samples, cfg->variance_threshold, keys, d_count);
+    HIPCHK(hipMemcpyAsync(ctx->h_pinned + 2, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint32_t n_noisy = ctx->h_pinned[2];
+    if (n_noisy == 0) return PTX_OK;           // renderloop/parallel.rs:98-100
+    uint32_t n_work = n_noisy;
+    if ((uint64_t)n_noisy <= cfg->max_samples_per_pass) {
+        // nothing is truncated, so the descending sort (parallel.rs:102-106) cannot change any pixel's result
+        hipLaunchKernelGGL(k_compact_noisy, dim3(grid), dim3(256), 0, ctx->stream, ctx->wl_pixel, keys, n, work, d_count + 1);
+    } else {
+        // truncate(max): stable descending sort by error, ties in row-major pixel order as on the CPU
+        if (ctx->world != 1) return fail(ctx, PTX_ERR_UNSUPPORTED, "max_samples_per_pass below the noisy count needs world == 1");
+        n_work = (uint32_t)cfg->max_samples_per_pass;
+        if (n_work == 0) return PTX_OK;
+        // keys are indexed in tile order; rebuild them in row-major order: owned == all pixels when world == 1
+        uint32_t* rm_keys = ctx->list_d; uint32_t* rm_idx = reinterpret_cast<uint32_t*>(ctx->list_a);
+        uint32_t* s_keys = rm_idx + n; uint32_t* s_idx = rm_idx + 2 * (size_t)n;
+        hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, rm_idx, n);
+        // scatter: rm_keys[pixel] = keys[i] — done as a gather through a one-off inverse built by sorting (pixel, i)
+        {
+            size_t tmp = 0;
+            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, ctx->wl_pixel, s_keys, keys, rm_keys, (int)n, 0, 32, ctx->stream);
+            if (tmp > ctx->cub_tmp_bytes) { if (ctx->cub_tmp) (void)hipFree(ctx->cub_tmp); ctx->cub_tmp = nullptr; HIPCHK(hipMalloc(&ctx->cub_tmp, tmp)); ctx->cub_tmp_bytes = tmp; }
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp, tmp, ctx->wl_pixel, s_keys, keys, rm_keys, (int)n, 0, 32, ctx->stream));
+        }
+        {
+            size_t tmp = 0;
+            (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, rm_keys, s_keys, rm_idx, s_idx, (int)n, 0, 32, ctx->stream);
+            if (tmp > ctx->cub_tmp_bytes) { if (ctx->cub_tmp) (void)hipFree(ctx->cub_tmp); ctx->cub_tmp = nullptr; HIPCHK(hipMalloc(&ctx->cub_tmp, tmp)); ctx->cub_tmp_bytes = tmp; }
+            HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(ctx->cub_tmp, tmp, rm_keys, s_keys, rm_idx, s_idx, (int)n, 0, 32, ctx->stream));
+        }
+        HIPCHK(hipMemcpyAsync(work, s_idx, (size_t)n_work * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    Target tg{};
+    tg.sum = ctx->fb_sum; tg.sum_sq = ctx->fb_sum_sq; tg.counts = ctx->fb_counts;
+    // sample_index = the pixel's own sample count (parallel.rs:109-114)
+    st = run_paths(ctx, work, nullptr, ctx->fb_counts, 0, n_work, ctx->fb_w, ctx->fb_h, max_bounces, tg, false);
+    if (st != PTX_OK) return st;
+    add_primary_count(ctx, n_work);
+    *out_rendered = n_work;
+    return check_device_error(ctx);
+}
+
+int32_t ptx_fb_stats(PtxContext* ctx, uint32_t* out_min, uint32_t* out_max, uint64_t* out_total) {
+    REQUIRE_CTX();
+    if (!ctx->fb_sum) return fail(ctx, PTX_ERR_INVALID, "no framebuffer: call ptx_fb_reset");
+    int32_t st = ensure_worklist(ctx, ctx->fb_w, ctx->fb_h);
+    if (st != PTX_OK) return st;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&ctx->ctrs[MAX_ITERS - 2]);
+    const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+    HIPCHK(hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->wl_n) hipLaunchKernelGGL(k_fb_stats, dim3(std::min<uint32_t>(1024, (ctx->wl_n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->wl_pixel, ctx->wl_n,
+                                      ctx->fb_counts, d, d + 1, reinterpret_cast<unsigned long long*>(d + 2));
+    HIPCHK(hipMemcpyAsync(ctx->h_pinned + 4, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (out_min) *out_min = ctx->wl_n ? ctx->h_pinned[4] : 0;
+    if (out_max) *out_max = ctx->h_pinned[5];
+    if (out_total) std::memcpy(out_total, ctx->h_pinned + 6, 8);
+    return PTX_OK;
+}
+
+int32_t ptx_fb_read(PtxContext* ctx, float* out_sum, float* out_sum_sq, uint32_t* out_counts) {
+    REQUIRE_CTX();
+    if (!ctx->fb_sum) return fail(ctx, PTX_ERR_INVALID, "no framebuffer: call ptx_fb_reset");
+    const uint64_t npx = (uint64_t)ctx->fb_w * ctx->fb_h;
+    if (out_sum) HIPCHK(hipMemcpyAsync(out_sum, ctx->fb_sum, npx * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_sum_sq && ctx->fb_sum_sq) HIPCHK(hipMemcpyAsync(out_sum_sq, ctx->fb_sum_sq, npx * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_counts) HIPCHK(hipMemcpyAsync(out_counts, ctx->fb_counts, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return check_device_error(ctx);
+}
+
+int32_t ptx_fb_read_mean(PtxContext* ctx, float* out_mean) {
+    REQUIRE_CTX();
+    if (!ctx->fb_sum || !out_mean) return fail(ctx, PTX_ERR_INVALID, "no framebuffer or null output");
+    const uint64_t npx = (uint64_t)ctx->fb_w * ctx->fb_h;
+    int32_t st = ensure_images(ctx, npx);
+    if (st != PTX_OK) return st;
+    hipLaunchKernelGGL(k_mean, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, ctx->stream, ctx->fb_sum, ctx->fb_counts, (uint32_t)npx, ctx->img);
+    HIPCHK(hipMemcpyAsync(out_mean, ctx->img, npx * 12, hipMemcpyDeviceToHost, ctx->stream));
+    return check_device_error(ctx);
+}
+
+int32_t ptx_fb_export_dev(PtxContext* ctx, float* d_sum, float* d_sum_sq, uint32_t* d_counts) {
+    REQUIRE_CTX();
+    if (!ctx->fb_sum) return fail(ctx, PTX_ERR_INVALID, "no framebuffer: call ptx_fb_reset");
+    const uint64_t npx = (uint64_t)ctx->fb_w * ctx->fb_h;
+    if (d_sum) HIPCHK(hipMemcpyAsync(d_sum, ctx->fb_sum, npx * 12, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_sum_sq && ctx->fb_sum_sq) HIPCHK(hipMemcpyAsync(d_sum_sq, ctx->fb_sum_sq, npx * 12, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_counts) HIPCHK(hipMemcpyAsync(d_counts, ctx->fb_counts, npx * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return PTX_OK;
+}
+
+// ---- parity / measurement ------------------------------------------------------------------
+int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t mode, PtxHitRecord* out_hits, uint8_t* out_any) {
+    REQUIRE_SCENE();
+    if (n == 0) return PTX_OK;
+    if (!rays || (mode == PTX_TRACE_CLOSEST && !out_hits) || (mode == PTX_TRACE_ANY && !out_any) || (mode != PTX_TRACE_CLOSEST && mode != PTX_TRACE_ANY))
+        return fail(ctx, PTX_ERR_INVALID, "bad trace_batch arguments");
+    PtxRay* d_rays = nullptr; void* d_out = nullptr;
+    const size_t out_bytes = mode == PTX_TRACE_ANY ? n : n * sizeof(PtxHitRecord);
+    HIPCHK(hipMalloc((void**)&d_rays, n * sizeof(PtxRay)));
+    if (hipMalloc(&d_out, out_bytes) != hipSuccess) { (void)hipFree(d_rays); return fail(ctx, PTX_ERR_HIP, "hipMalloc failed"); }
+    int32_t st = PTX_OK;
+    do {
+        if (hipMemcpyAsync(d_rays, rays, n * sizeof(PtxRay), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = fail(ctx, PTX_ERR_HIP, "H2D copy failed"); break; }
+        const int grid = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
+        ScopedEvent* ev = new ScopedEvent(ctx, mode == PTX_TRACE_ANY ? CLS_SHADOW : CLS_EXTEND);
+        if (mode == PTX_TRACE_ANY) {
+            if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, ctx->ovf, ctx->d_counters, ctx->d_err);
+            else hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, ctx->ovf, ctx->d_counters, ctx->d_err);
+        } else {
+            if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, ctx->ovf, ctx->d_counters, ctx->d_err);
+            else hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, ctx->ovf, ctx->d_counters, ctx->d_err);
+        }
+        delete ev;
+        if (hipMemcpyAsync(mode == PTX_TRACE_ANY ? (void*)out_any : (void*)out_hits, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { st = fail(ctx, PTX_ERR_HIP, "D2H copy failed"); break; }
+        st = check_device_error(ctx);
+    } while (0);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_rays); (void)hipFree(d_out);
+    return st;
+}
+
+int32_t ptx_generate_primary_rays(PtxContext* ctx, uint32_t w, uint32_t h, uint32_t sample_index, PtxRay* out_rays) {
+    REQUIRE_CAMERA();
+    if (!w || !h || !out_rays) return fail(ctx, PTX_ERR_INVALID, "bad arguments");
+    const uint32_t n = w * h;
+    int32_t st = ensure_lists(ctx, (uint64_t)n * 3);   // list_a then holds n PtxRay (28 B <= 36 B)
+    if (st != PTX_OK) return st;
+    uint32_t* ident = ctx->list_b;
+    hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ident, n);
+    PtxRay* d_rays = reinterpret_cast<PtxRay*>(ctx->list_a);
+    PathArrays none{};
+    hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->cam, none, ident, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, sample_index, n, w, h, (uint32_t*)nullptr, (IterCtr*)nullptr, 0u, d_rays);
+    HIPCHK(hipMemcpyAsync(out_rays, d_rays, (size_t)n * sizeof(PtxRay), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PTX_OK;
+}
+
+int32_t ptx_set_counting(PtxContext* ctx, int32_t enabled) { REQUIRE_CTX(); ctx->counting = enabled != 0; return PTX_OK; }
+int32_t ptx_reset_counters(PtxContext* ctx) {
+    REQUIRE_CTX();
+    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(DevCounters), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PTX_OK;
+}
+int32_t ptx_get_counters(PtxContext* ctx, PtxCounters* out) {
+    REQUIRE_CTX();
+    if (!out) return fail(ctx, PTX_ERR_INVALID, "null output");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out, ctx->d_counters, sizeof(PtxCounters), hipMemcpyDeviceToHost));
+    return PTX_OK;
+}
+int32_t ptx_set_profiling(PtxContext* ctx, int32_t enabled) { REQUIRE_CTX(); drain_events(ctx); ctx->profiling = enabled != 0; return PTX_OK; }
+int32_t ptx_reset_timings(PtxContext* ctx) { REQUIRE_CTX(); drain_events(ctx); ctx->timings = PtxTimings{}; return PTX_OK; }
+int32_t ptx_get_timings(PtxContext* ctx, PtxTimings* out) {
+    REQUIRE_CTX();
+    if (!out) return fail(ctx, PTX_ERR_INVALID, "null output");
+    drain_events(ctx);
+    *out = ctx->timings;
+    return PTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// pt_types.h — HBM layouts of the render core (see DESIGN.md "Data layout").
+#pragma once
+#include "pt_vec.h"
+#include "ptx_core.h"
+
+namespace ptd {
+
+// ---- BVH node record: 128 B = one L2 line, up to 4 children ------------------
+// The reference's Bvh8Node stores 8 full-precision child boxes SoA in 256 B
+// (accel/bvh.rs:86-98), of which its own builder only ever fills 1-3
+// (SURVEY.md F8b).  The device record keeps the surviving slots, in slot
+// order, with the same f32 values: child k is two float4
+//   c[2k]   = (min.x, min.y, min.z, max.x)
+//   c[2k+1] = (max.y, max.z, child_word, meta)
+// child_word: bit31 = leaf; leaf = 1<<31 | (count-1)<<24 | prim_start (start
+// relative to the owning BVH's leaf array, as in the reference); internal =
+// record index relative to the owning BVH's first record.
+// meta (child 0 only): bits 0-2 = number of children in this record (1..4),
+// bit 3 = the node continues in the next record (a host that really fills
+// 5-8 slots), bits 8-11 = popcount(valid_mask) of the whole node (counters).
+struct NodeRec { float4 c[8]; };
+static_assert(sizeof(NodeRec) == 128, "node record must be one 128-byte line");
+
+constexpr uint32_t LEAF_FLAG = 0x80000000u;
+constexpr uint32_t PRIM_START_MASK = 0x00FFFFFFu;
+constexpr uint32_t PRIM_COUNT_SHIFT = 24;
+constexpr uint32_t PRIM_COUNT_MASK = 0x7Fu;
+
+// ---- leaf triangle record: 48 B, in primitive_indices order -------------------
+//   a = (v0.x, v0.y, v0.z, e1.x)  b = (e1.y, e1.z, e2.x, e2.y)  c = (e2.z, tri_idx, -, -)
+// e1 = v1 - v0, e2 = v2 - v0 are the first two operations of intersect_triangle
+// (shape/triangle_mesh.rs:70-71) done once at upload: same inputs, same
+// rounding, and two index indirections fewer per test.
+struct TriRec { float4 a, b, c; };
+static_assert(sizeof(TriRec) == 48, "triangle record");
+
+// ---- instance record: 128 B ---------------------------------------------------
+//   m[0..2] inverse_transform columns packed (x.xyz,y.x | y.yz,z.xy | z.z,w.xyz)
+//   m[3]    (bounds_min.xyz, bounds_max.x)      -- the Blas-level item box
+//   m[4]    (bounds_max.y, bounds_max.z, node_base, tri_base)
+//   m[5..7] transform columns packed like m[0..2] (read only on an accepted hit)
+struct InstRec { float4 m[8]; };
+static_assert(sizeof(InstRec) == 128, "instance record");
+
+// normal_matrix 3x3 part (x.xyz, y.xyz, z.xyz) + mesh id: read once per path vertex
+struct InstShade { float n[9]; uint32_t mesh_id; uint32_t pad[2]; };
+
+struct MeshRec {
+    uint32_t pos_base;      // float index into positions
+    uint32_t nrm_base;      // float index into normals, 0xFFFFFFFF = none
+    uint32_t uv_base;       // float index into uvs, 0xFFFFFFFF = none
+    uint32_t idx_base;      // u32 index into indices
+    uint32_t material_id;
+    uint32_t node_base, tri_base, n_triangles;
+};
+
+struct TexRec {
+    uint32_t width, height;
+    uint64_t offset;        // float index into the texel pool; ~0ull = SolidColor
+    float solid[3];
+    uint32_t pad;
+};
+
+struct SceneDev {
+    const NodeRec* nodes;          // TLAS records first, then every mesh BVH
+    const uint32_t* tlas_prims;    // TLAS primitive_indices (instance ids)
+    const TriRec* tris;
+    const InstRec* inst;
+    const InstShade* inst_shade;
+    const MeshRec* meshes;
+    const float* positions;
+    const float* normals;
+    const float* uvs;
+    const uint32_t* indices;
+    const PtxMaterial* materials;
+    const TexRec* textures;
+    const float* texels;
+    // sky
+    TexRec sky_tex;
+    const float* sky_marginal;
+    const float* sky_conditional;
+    uint32_t sky_w, sky_h;
+    float sky_total_weight, sky_rotation;
+    // sun
+    uint32_t sun_enabled;
+    float sun_dir[3], sun_color[3], sun_cos_angle, sun_pdf;
+    // blue noise (64x64 Vec2 each)
+    const float* bn_pixel;
+    const float* bn_lens;
+    uint32_t bn_size;
+    uint32_t n_tlas_nodes;         // 0 = empty TLAS (Tlas::build with no instances)
+    uint32_t has_sss;
+};
+
+struct CameraDev {
+    float inv_vp[16];
+    float aperture, focus_distance;
+    float right[3], up[3];
+};
+
+// Per-wave event counters behind ptx_get_counters.
+struct DevCounters { unsigned long long v[sizeof(PtxCounters) / 8]; };
+enum CounterId {
+    C_RAYS_CLOSEST, C_RAYS_ANY, C_NODE_VISITS, C_NODE_CHILDREN, C_PRIM_INDEX_READS, C_TRI_TESTS,
+    C_INST_ENTRIES, C_INST_HITS, C_HITDATA, C_MATERIAL, C_TEXTURE, C_CDF_PROBES, C_SKY_PDF,
+    C_SKY_TEXEL, C_PRIMARY, C_PIXEL_SAMPLES, C_SSS_STEPS, C_COUNT
+};
+static_assert(C_COUNT == sizeof(PtxCounters) / 8, "counter ids must mirror PtxCounters");
+
+}  // namespace ptd
