@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline measurement on MI355X.
+
+Metric (BASELINE.json): Mrays/s + s/frame, Bistro 1080p 64 spp, 1/2/4/8 MI355X,
+% of the HBM roofline, next to the host-CPU path.
+
+A "step" is one whole frame: `for sample in 0..spp { render_pass; accumulate }`
+(main.rs:124-133) on the device-resident framebuffer, scene already in HBM.
+With N > 1 the frame is split by interleaved 8x8 pixel tiles (scene replicated)
+and the per-pixel sum / sum_sq / count buffers are combined with one RCCL
+all-reduce per frame (every rank contributes zeros outside its tiles, so the
+combined buffers are bit-identical to the single-GPU ones).  Total work is
+fixed as N grows: "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def extend_bytes(c):
+    """Algorithmic bytes of the closest-hit (extend) traversal only: SURVEY.md §8(d) terms
+    node + prim-index + triangle + instance, with the any-hit share removed."""
+    nv = c["node_visits"] - c["any_node_visits"]
+    nc = c["node_children"] - c["any_node_children"]
+    pr = c["prim_index_reads"] - c["any_prim_index_reads"]
+    tt = c["triangle_tests"] - c["any_triangle_tests"]
+    ie = c["instance_entries"] - c["any_instance_entries"]
+    return 4 * nv + 28 * nc + 4 * pr + 48 * tt + 64 * ie + 128 * c["instance_hits"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="bistro_like")
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--bounces", type=int, default=16)      # PathTracer<16> of the app (app.rs:152)
+    ap.add_argument("--flags", type=int, default=1)         # app lighting: HDR sky IS + sun
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render core has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = ge.load_package()
+    w, h, spp = args.width, args.height, args.spp
+    t0 = time.time()
+    scene = pkg.Scene.procedural(args.scene, args.seed, args.detail, args.flags)
+    build_s = time.time() - t0
+    cam = scene.default_camera(w / h)
+    renderer = pkg.PathTracer(args.bounces)
+    loop = pkg.HipRenderLoop(local_rank)
+    loop.set_partition(rank, world)
+    fb = pkg.DeviceFramebuffer(loop, w, h, adaptive=True)
+    loop._bind(scene, cam)   # upload once: inputs are resident in HBM before anything is timed
+
+    if world > 1:
+        d_sum = torch.empty(h * w * 3, dtype=torch.float32, device="cuda")
+        d_sq = torch.empty(h * w * 3, dtype=torch.float32, device="cuda")
+        d_cnt = torch.empty(h * w, dtype=torch.int32, device="cuda")
+
+    def frame():
+        fb.reset()
+        fb.render_passes(scene, cam, renderer, 0, spp)
+        if world > 1:
+            fb.export_dev(d_sum.data_ptr(), d_sq.data_ptr(), d_cnt.data_ptr())
+            loop.sync()                       # library stream -> visible to torch's stream
+            pkg.render.combine_framebuffers(dist, (d_sum, d_sq, d_cnt))   # RCCL over xGMI: disjoint tiles + zeros => exact
+
+    def fence():
+        loop.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # counted frame (untimed; counted kernels are slower): rays and algorithmic bytes per frame
+    loop.set_counting(True)
+    loop.reset_counters()
+    frame()
+    fence()
+    cnt = loop.counters()
+    loop.set_counting(False)
+    if world > 1:
+        keys = sorted(cnt)
+        t = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        cnt = {k: int(v) for k, v in zip(keys, t.tolist())}
+
+    for _ in range(args.warmup):
+        frame()
+    fence()
+    loop.set_profiling(True)
+    loop.reset_timings()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tim = loop.timings()
+    loop.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    sec_per_frame = elapsed / args.steps
+    rays_per_frame = cnt["rays_closest"] + cnt["rays_any"]
+    primary_per_frame = w * h * spp
+    mrays = rays_per_frame / sec_per_frame / 1e6
+    abytes_frame = pkg._abi.algorithmic_bytes(cnt, texel_bytes_per_lookup=48, adaptive=True)
+
+    # roofline of the dominant kernel (k_extend), rank 0's launches, HIP events on the library stream
+    ext_launches = max(1, tim["extend_launches"])
+    ext_ms = tim["extend_ms"] / ext_launches
+    # rank 0 traced 1/world of the frame's extend work (tile interleave): per-launch bytes on this rank
+    ext_bytes_launch = extend_bytes(cnt) / world * args.steps / ext_launches
+    achieved = ext_bytes_launch / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": round(ext_bytes_launch), "avg_launch_ms": round(ext_ms, 4),
+                "launches": int(ext_launches)}
+    traffic_file = os.path.join(ROOT, "profiles", "extend_traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            roofline["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    out = {
+        "metric": "Mrays/s (all ray types) on Bistro-like 1080p 64spp; s/frame = ms_per_step/1000",
+        "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(sec_per_frame * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.scene} (procedural stand-in, seed {args.seed}, detail {args.detail}) "
+                               f"{w}x{h} {spp}spp PathTracer<{args.bounces}> env-map IS + sun + MIS, tile-interleaved over {world} GPU(s)",
+                   "triangles": scene.stats()["triangles"], "instances": scene.stats()["instances"],
+                   "parallelism": f"tiles8x8 mod {world}" + (" + RCCL all-reduce" if world > 1 else "")},
+        "sec_per_frame": round(sec_per_frame, 4),
+        "mprimary_per_s": round(primary_per_frame / sec_per_frame / 1e6, 2),
+        "rays_per_frame": rays_per_frame,
+        "algorithmic_bytes_per_frame": abytes_frame,
+        "frame_hbm_frac": round(abytes_frame / sec_per_frame / 1e9 / HBM_PEAK_GBS, 5),
+        "kernel_ms_per_frame": {k: round(tim[k] / args.steps, 3) for k in
+                                ("raygen_ms", "extend_ms", "shade_ms", "shadow_ms", "accumulate_ms")},
+        "scene_build_s": round(build_s, 2),
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pkg, scene, cam, w, h, args.bounces, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pkg, scene, cam, w, h, bounces, budget_s):
+    """The C++ restatement of the reference's CPU path (oracle, libm build) on this box's host
+    cores, pixel-parallel like rayon's into_par_iter, on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_py import Oracle
+    oracle = Oracle("libm")
+    threads = max(1, min(16, os.cpu_count() or 1))   # the GPU box gives one job a 16-CPU share
+    oracle.set_threads(threads)
+    osc = oracle.scene(scene)
+    rng = np.random.default_rng(1)
+
+    def sample_tiles(n_tiles):
+        tx_n, ty_n = (w + 7) // 8, (h + 7) // 8
+        ids = rng.choice(tx_n * ty_n, size=min(n_tiles, tx_n * ty_n), replace=False)
+        xs, ys = [], []
+        for t in ids:
+            tx, ty = t % tx_n, t // tx_n
+            for ly in range(8):
+                for lx in range(8):
+                    x, y = tx * 8 + lx, ty * 8 + ly
+                    if x < w and y < h:
+                        xs.append(x); ys.append(y)
+        return np.stack([np.array(xs), np.array(ys), np.zeros(len(xs), dtype=np.int64)], axis=1).astype(np.uint32)
+
+    # calibrate on 64 tiles, then size the sample for ~budget_s
+    work = sample_tiles(64)
+    t0 = time.perf_counter()
+    osc.render_pixels(cam, w, h, work, bounces)
+    cal = time.perf_counter() - t0
+    per_px = cal / len(work)
+    n_tiles = int(max(64, min(budget_s / max(per_px, 1e-9) / 64, (w * h) // 64)))
+    work = sample_tiles(n_tiles)
+    oracle.reset_counters()
+    t0 = time.perf_counter()
+    osc.render_pixels(cam, w, h, work, bounces)
+    dt = time.perf_counter() - t0
+    c = oracle.counters()
+    rays = c["rays_closest"] + c["rays_any"]
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{len(work)} pixel-samples (random 8x8 tiles, sample_index 0) of the same scene/camera/bounces, "
+                      f"{dt:.1f} s; C++ restatement of the reference CPU path (no Rust toolchain here), AVX2 node test",
+            "mprimary_per_s": round(len(work) / dt / 1e6, 4),
+            "sec_per_frame_extrapolated": round(dt / len(work) * w * h * 64, 1)}
+
+
+if __name__ == "__main__":
+    main()

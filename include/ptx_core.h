@@ -216,6 +216,14 @@ typedef struct PtxCounters {
     uint64_t primary_rays;
     uint64_t pixel_samples_written;
     uint64_t sss_steps;
+    /* the share of the five traversal counts above that hit_any rays caused
+     * (already included in the totals); lets a caller price closest-hit
+     * (extend) and any-hit (shadow) traversal separately */
+    uint64_t any_node_visits;
+    uint64_t any_node_children;
+    uint64_t any_prim_index_reads;
+    uint64_t any_triangle_tests;
+    uint64_t any_instance_entries;
 } PtxCounters;
 
 /* `AdaptiveSamplingConfig` (renderloop/parallel.rs:13-17). */
@@ -317,6 +325,11 @@ int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t
  * bluenoise.rs:156-172, camera.rs:66-95), for the RNG-seed parity check. */
 int32_t ptx_generate_primary_rays(PtxContext* ctx, uint32_t width, uint32_t height,
                                   uint32_t sample_index, PtxRay* out_rays);
+
+/* Test hook: evaluates the kernels' own f32 transcendentals (fn: 0 sin, 1 cos,
+ * 2 exp, 3 ln, 4 atan2(x, y), 5 asin, 6/7 sin/cos of the fused sincos) on the
+ * device, so tests can pin them against glibc and against the oracle. */
+int32_t ptx_debug_math(PtxContext* ctx, int32_t fn, const float* x, const float* y, uint64_t n, float* out);
 
 int32_t ptx_set_counting(PtxContext* ctx, int32_t enabled);   /* counted kernels are slower */
 int32_t ptx_reset_counters(PtxContext* ctx);

@@ -128,6 +128,7 @@ inline Vec4 mul_vec4(const float* m, Vec4 v) {
 // ------------------------------------------------------------- counters -------
 struct Counters : PtxCounters { Counters() { std::memset(this, 0, sizeof(*this)); } };
 thread_local Counters tl_cnt;
+thread_local bool tl_in_any = false;   // inside Scene::hit_any: also feed the any_* share
 Counters g_cnt;
 std::mutex g_cnt_mutex;
 void flush_counters() {
@@ -248,6 +249,8 @@ bool traverse_any(const PtxBvh8& bvh, const Ray& ray, F&& test_primitive) {
         node_intersect(node, ray, ray.t_max, &hit_mask, distances);
         tl_cnt.node_visits += 1;
         tl_cnt.node_children += (uint64_t)__builtin_popcount(node.valid_mask);
+        tl_cnt.any_node_visits += 1;
+        tl_cnt.any_node_children += (uint64_t)__builtin_popcount(node.valid_mask);
         const uint8_t active = hit_mask & node.valid_mask;
         if (active == 0) continue;
         uint8_t mask = active;
@@ -260,6 +263,7 @@ bool traverse_any(const PtxBvh8& bvh, const Ray& ray, F&& test_primitive) {
                 const size_t prim_count = ((child >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1;
                 for (size_t i = prim_start; i < prim_start + prim_count; ++i) {
                     tl_cnt.prim_index_reads += 1;
+                    tl_cnt.any_prim_index_reads += 1;
                     if (test_primitive(bvh.primitive_indices[i], ray)) return true;
                 }
             } else {
@@ -280,6 +284,7 @@ inline Vec3 load3(const float* p, uint32_t i) { return Vec3{p[3 * (size_t)i], p[
 // shape/triangle_mesh.rs:63-100
 inline std::optional<std::pair<float, Vec2>> intersect_triangle(const PtxMesh& m, size_t tri_idx, const Ray& ray) {
     tl_cnt.triangle_tests += 1;
+    if (tl_in_any) tl_cnt.any_triangle_tests += 1;
     const uint32_t* tri = &m.indices[3 * tri_idx];
     const Vec3 v0 = load3(m.positions, tri[0]), v1 = load3(m.positions, tri[1]), v2 = load3(m.positions, tri[2]);
     const Vec3 edge1 = v1 - v0, edge2 = v2 - v0;
@@ -390,6 +395,7 @@ inline std::optional<HitData> instance_hit(const PtxInstance& inst, const Ray& r
 }
 inline bool instance_hit_any(const PtxInstance& inst, const Ray& ray, const Blas& blas) {
     tl_cnt.instance_entries += 1;
+    tl_cnt.any_instance_entries += 1;
     const Vec3 local_origin = transform_point3(inst.inverse_transform, ray.origin);
     const Vec3 local_direction = transform_vector3(inst.inverse_transform, ray.direction);
     return blas_hit_any(blas, Ray::make(local_origin, local_direction));
@@ -413,10 +419,13 @@ struct Scene {
     }
     bool hit_any(const Ray& ray) const {
         tl_cnt.rays_any += 1;
-        return traverse_any(d.tlas, ray, [&](uint32_t inst_idx, const Ray& rr) {
+        tl_in_any = true;
+        const bool r = traverse_any(d.tlas, ray, [&](uint32_t inst_idx, const Ray& rr) {
             const PtxInstance& inst = d.instances[inst_idx];
             return instance_hit_any(inst, rr, blases[inst.blas_index]);
         });
+        tl_in_any = false;
+        return r;
     }
     const PtxMaterial& get_material(uint32_t id) const { tl_cnt.material_fetches += 1; return d.materials[id]; }
     Vec3 sample_texture(uint32_t id, Vec2 uv) const { return texture_sample(d.textures[id], uv, &tl_cnt.texture_lookups); }

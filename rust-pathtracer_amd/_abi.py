@@ -131,6 +131,7 @@ COUNTER_FIELDS = [
     "triangle_tests", "instance_entries", "instance_hits", "hitdata_built",
     "material_fetches", "texture_lookups", "cdf_probes", "sky_pdf_evals",
     "sky_texel_lookups", "primary_rays", "pixel_samples_written", "sss_steps",
+    "any_node_visits", "any_node_children", "any_prim_index_reads", "any_triangle_tests", "any_instance_entries",
 ]
 
 

@@ -106,6 +106,13 @@ PT_DEV void flush_lane_cnt(DevCounters* dc, const LaneCnt& lc, uint32_t rays, bo
     wave_add(&dc->v[C_TRI_TESTS], lc.tri_tests);
     wave_add(&dc->v[C_INST_ENTRIES], lc.inst_entries);
     wave_add(&dc->v[C_INST_HITS], lc.inst_hits);
+    if (any) {
+        wave_add(&dc->v[C_ANY_NODE_VISITS], lc.node_visits);
+        wave_add(&dc->v[C_ANY_NODE_CHILDREN], lc.node_children);
+        wave_add(&dc->v[C_ANY_PRIM_INDEX_READS], lc.prim_reads);
+        wave_add(&dc->v[C_ANY_TRI_TESTS], lc.tri_tests);
+        wave_add(&dc->v[C_ANY_INST_ENTRIES], lc.inst_entries);
+    }
 }
 
 // ================================================================ kernels ======
@@ -756,6 +763,24 @@ __global__ void k_mean(const float* sum, const uint32_t* counts, uint32_t n_pixe
     const size_t f = (size_t)i * 3;
     if (c == 0u) { out[f] = 0.0f; out[f + 1] = 0.0f; out[f + 2] = 0.0f; }
     else { const float cf = (float)c; out[f] = sum[f] / cf; out[f + 1] = sum[f + 1] / cf; out[f + 2] = sum[f + 2] / cf; }
+}
+
+// ---- test hook: the kernels' transcendental implementations on a caller's inputs --------
+__global__ void k_debug_math(int fn, const float* x, const float* y, uint64_t n, float* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (fn) {
+        case 0: r = d_sinf(x[i]); break;
+        case 1: r = d_cosf(x[i]); break;
+        case 2: r = d_expf(x[i]); break;
+        case 3: r = d_logf(x[i]); break;
+        case 4: r = d_atan2f(x[i], y[i]); break;
+        case 5: r = d_asinf(x[i]); break;
+        case 6: { float s, c; d_sincosf(x[i], &s, &c); r = s; break; }
+        default: { float s, c; d_sincosf(x[i], &s, &c); r = c; break; }
+    }
+    out[i] = r;
 }
 
 }  // namespace
@@ -1532,6 +1557,23 @@ int32_t ptx_generate_primary_rays(PtxContext* ctx, uint32_t w, uint32_t h, uint3
     HIPCHK(hipMemcpyAsync(out_rays, d_rays, (size_t)n * sizeof(PtxRay), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return PTX_OK;
+}
+
+int32_t ptx_debug_math(PtxContext* ctx, int32_t fn, const float* x, const float* y, uint64_t n, float* out) {
+    REQUIRE_CTX();
+    if (!x || !y || !out || n == 0) return fail(ctx, PTX_ERR_INVALID, "bad arguments");
+    float* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, n * 3 * sizeof(float)));
+    int32_t st = PTX_OK;
+    if (hipMemcpyAsync(d, x, n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d + n, y, n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = fail(ctx, PTX_ERR_HIP, "H2D copy failed");
+    if (st == PTX_OK) {
+        hipLaunchKernelGGL(k_debug_math, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, fn, d, d + n, n, d + 2 * n);
+        if (hipMemcpyAsync(out, d + 2 * n, n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = fail(ctx, PTX_ERR_HIP, "D2H copy failed");
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return st;
 }
 
 int32_t ptx_set_counting(PtxContext* ctx, int32_t enabled) { REQUIRE_CTX(); ctx->counting = enabled != 0; return PTX_OK; }

@@ -206,7 +206,7 @@ PT_DEV bool trace_ray(const SceneDev& S, const V3 wo, const V3 wd, const float t
                         const uint32_t inst_idx = S.tlas_prims[start + j];
                         const InstRec& ir = S.inst[inst_idx];
                         const float4 ia = ir.m[0], ib = ir.m[1], ic = ir.m[2], b0 = ir.m[3], b1 = ir.m[4];
-                        if (CNT) { lc.prim_reads += 2; lc.inst_entries++; lc.node_visits++; lc.node_children++; }
+                        if (CNT) { lc.prim_reads++; lc.inst_entries++; lc.node_visits++; lc.node_children++; }
                         const V3 lo = xf_point(ia, ib, ic, wo);
                         const V3 ld = xf_vector(ia, ib, ic, wd);
                         const V3 linv = v3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
@@ -216,6 +216,7 @@ PT_DEV bool trace_ray(const SceneDev& S, const V3 wo, const V3 wd, const float t
                         const bool bhit = box_test(blo, bhi, lo, linv, tmin, PT_INF, &te);
                         if (!bhit) continue;
                         if (!ANY && te >= PT_INF) continue;
+                        if (CNT) lc.prim_reads++;   // the Blas leaf's own primitive index
                         // descend into the mesh BVH (TriangleMesh::hit: closest_t = local t_max = +inf)
                         c_rec = rec; c_k = k; c_j = j + 1u;
                         in_mesh = true; entered = true;

@@ -103,7 +103,8 @@ struct DevCounters { unsigned long long v[sizeof(PtxCounters) / 8]; };
 enum CounterId {
     C_RAYS_CLOSEST, C_RAYS_ANY, C_NODE_VISITS, C_NODE_CHILDREN, C_PRIM_INDEX_READS, C_TRI_TESTS,
     C_INST_ENTRIES, C_INST_HITS, C_HITDATA, C_MATERIAL, C_TEXTURE, C_CDF_PROBES, C_SKY_PDF,
-    C_SKY_TEXEL, C_PRIMARY, C_PIXEL_SAMPLES, C_SSS_STEPS, C_COUNT
+    C_SKY_TEXEL, C_PRIMARY, C_PIXEL_SAMPLES, C_SSS_STEPS,
+    C_ANY_NODE_VISITS, C_ANY_NODE_CHILDREN, C_ANY_PRIM_INDEX_READS, C_ANY_TRI_TESTS, C_ANY_INST_ENTRIES, C_COUNT
 };
 static_assert(C_COUNT == sizeof(PtxCounters) / 8, "counter ids must mirror PtxCounters");
 

@@ -22,7 +22,7 @@ EXPORTS = [
     "ptx_fb_reset", "ptx_fb_render_passes", "ptx_fb_adaptive_pass", "ptx_fb_stats", "ptx_fb_read",
     "ptx_fb_read_mean", "ptx_fb_export_dev", "ptx_sync", "ptx_trace_batch", "ptx_generate_primary_rays",
     "ptx_set_counting", "ptx_reset_counters", "ptx_get_counters", "ptx_set_profiling", "ptx_reset_timings",
-    "ptx_get_timings",
+    "ptx_get_timings", "ptx_debug_math",
 ]
 
 
@@ -70,6 +70,7 @@ def lib():
     L.ptx_set_profiling.argtypes = [vp, i32]
     L.ptx_reset_timings.argtypes = [vp]
     L.ptx_get_timings.argtypes = [vp, C.POINTER(abi.PtxTimings)]
+    L.ptx_debug_math.argtypes = [vp, i32, vp, vp, u64, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name != "ptx_last_error":
@@ -213,6 +214,14 @@ class HipRenderLoop:
         self._check(self.L.ptx_generate_primary_rays(self._h, width, height, sample_index, _p(out)), "ptx_generate_primary_rays")
         return out
 
+    def debug_math(self, fn, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(np.zeros_like(x) if y is None else y, dtype=np.float32)
+        out = np.zeros_like(x)
+        code = {"sin": 0, "cos": 1, "exp": 2, "ln": 3, "atan2": 4, "asin": 5, "sincos_s": 6, "sincos_c": 7}[fn]
+        self._check(self.L.ptx_debug_math(self._h, code, _p(x), _p(y), x.size, _p(out)), "ptx_debug_math")
+        return out
+
     # -- measurement -----------------------------------------------------------------
     def set_counting(self, on):
         self._check(self.L.ptx_set_counting(self._h, 1 if on else 0), "ptx_set_counting")
@@ -235,6 +244,31 @@ class HipRenderLoop:
         t = abi.PtxTimings()
         self._check(self.L.ptx_get_timings(self._h, C.byref(t)), "ptx_get_timings")
         return {n: getattr(t, n) for n, _ in abi.PtxTimings._fields_}
+
+
+TILE = 8
+
+
+def partition_pixels(width, height, rank, world):
+    """Row-major pixel indices rank `rank` of `world` owns: 8x8 tiles, tile_index % world == rank, in the tile order
+    the kernels use (one wave of primary rays == one tile).  Mirrors `ensure_worklist` in csrc/device/pt_core.hip."""
+    tx_n, ty_n = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    t = np.arange(tx_n * ty_n, dtype=np.int64)
+    t = t[t % world == rank]
+    ly, lx = np.meshgrid(np.arange(TILE), np.arange(TILE), indexing="ij")
+    x = (t % tx_n)[:, None] * TILE + lx.reshape(-1)[None, :]
+    y = (t // tx_n)[:, None] * TILE + ly.reshape(-1)[None, :]
+    ok = (x < width) & (y < height)
+    return (y * width + x)[ok].astype(np.uint32)
+
+
+def combine_framebuffers(dist, buffers):
+    """The one exchange step of a multi-GPU frame: every rank holds full-size sum / sum_sq / count buffers that are
+    zero outside its own tiles, so an all-reduce(SUM) (RCCL over xGMI on GPUs, gloo in the CPU tests) yields buffers
+    bit-identical to the single-GPU ones (x + 0 == x; ownership is disjoint)."""
+    for b in buffers:
+        dist.all_reduce(b)
+    return buffers
 
 
 class DeviceFramebuffer:

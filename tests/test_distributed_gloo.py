@@ -1,0 +1,84 @@
+"""The N > 1 path on CPU: two gloo ranks, each renders only the 8x8 tiles it owns (scene replicated), then the
+framebuffers are combined with the same `combine_framebuffers` all-reduce bench.py uses over RCCL.  The pixel work is
+done by the oracle here (no GPU in this tier); what is under test is the partition + exchange logic: the combined
+buffers must be bit-identical to a single-rank frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, spp, bounces, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from oracle_py import Oracle
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    scene = pkg.Scene.procedural("cornell", 1, 1.0, 0)
+    cam = scene.default_camera(w / h)
+    oracle = Oracle("det")
+    oracle.set_threads(2)
+    osc = oracle.scene(scene)
+    owned = pkg.render.partition_pixels(w, h, rank, world)
+    s = np.zeros((h * w, 3), dtype=np.float32)
+    q = np.zeros((h * w, 3), dtype=np.float32)
+    c = np.zeros(h * w, dtype=np.int32)
+    for k in range(spp):
+        work = np.stack([owned % w, owned // w, np.full(len(owned), k, dtype=np.uint32)], axis=1)
+        px = osc.render_pixels(cam, w, h, work, bounces)
+        s[owned] += px
+        q[owned] += px * px
+        c[owned] += 1
+    ts, tq, tc = torch.from_numpy(s), torch.from_numpy(q), torch.from_numpy(c)
+    pkg.render.combine_framebuffers(dist, (ts, tq, tc))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "combined.npz"), s=ts.numpy(), q=tq.numpy(), c=tc.numpy(), n_owned=len(owned))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partition_is_disjoint_and_complete(pkg):
+    for (w, h, world) in ((64, 36, 2), (100, 52, 3), (1920, 1080, 8), (7, 5, 2)):
+        parts = [pkg.render.partition_pixels(w, h, r, world) for r in range(world)]
+        allp = np.concatenate(parts)
+        assert len(allp) == w * h and len(np.unique(allp)) == w * h
+        if w * h > 10000:
+            sizes = np.array([len(p) for p in parts])
+            assert sizes.max() - sizes.min() <= 64 * 2 + 0.01 * sizes.mean()   # interleave balances the load
+    # one wave (64 consecutive entries) is one tile
+    p = pkg.render.partition_pixels(64, 32, 1, 2)[:64]
+    assert (p % 64).max() - (p % 64).min() == 7 and (p // 64).max() - (p // 64).min() == 7
+
+
+def test_two_rank_gloo_frame_equals_single_rank(pkg, oracle_det, tmp_path):
+    import torch.multiprocessing as mp
+    from oracle_py import OracleFramebuffer
+    w, h, spp, bounces, world = 48, 27, 3, 8, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, w, h, spp, bounces, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "combined.npz")
+    scene = pkg.Scene.procedural("cornell", 1, 1.0, 0)
+    cam = scene.default_camera(w / h)
+    fb = OracleFramebuffer(oracle_det.scene(scene), w, h, True)
+    fb.render_passes(cam, 0, spp, bounces)
+    s, q, c = fb.read()
+    assert 0 < int(got["n_owned"]) < w * h
+    assert np.array_equal(got["c"].reshape(h, w), c.astype(np.int32))
+    assert np.array_equal(got["s"].reshape(h, w, 3).view(np.uint32), s.view(np.uint32))
+    assert np.array_equal(got["q"].reshape(h, w, 3).view(np.uint32), q.view(np.uint32))
