@@ -118,22 +118,34 @@ PT_DEV void flush_lane_cnt(DevCounters* dc, const LaneCnt& lc, uint32_t rays, bo
 // ================================================================ kernels ======
 
 // ---- ray batches (ptx_trace_batch) ------------------------------------------------
+struct BatchSrc {
+    const PtxRay* rays;
+    PT_DEV void fetch(uint32_t i, V3* o, V3* d, float* tmax) const {
+        const PtxRay r = rays[i];
+        *o = v3(r.origin[0], r.origin[1], r.origin[2]);
+        *d = v3(r.direction[0], r.direction[1], r.direction[2]);
+        *tmax = r.t_max;
+    }
+};
+template <bool ANY>
+struct BatchSink {
+    PtxHitRecord* out_hits;
+    uint8_t* out_any;
+    template <class TV>
+    PT_DEV void store(uint32_t i, const TV& tv) const {
+        if (ANY) out_any[i] = tv.found ? 1 : 0;
+        else { PtxHitRecord o; o.inst_idx = tv.best.inst; o.tri_idx = tv.best.tri; o.t = tv.best.t; o.u = tv.best.u; o.v = tv.best.v; out_hits[i] = o; }
+    }
+};
 template <bool ANY, bool CNT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_batch(SceneDev S, const PtxRay* rays, uint64_t n, PtxHitRecord* out_hits,
-                                                             uint8_t* out_any, uint2* ovf, DevCounters* dc, uint32_t* err) {
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_batch(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
+                                                             uint8_t* out_any, uint32_t* work, uint2* ovf, DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
     LaneCnt lc = {0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, e = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TRACE_BLOCK) {
-        const PtxRay r = rays[i];
-        Hit h;
-        h.inst = PTX_MISS; h.tri = PTX_MISS; h.t = PT_INF; h.u = 0.0f; h.v = 0.0f;
-        const bool res = trace_ray<ANY, CNT>(S, v3(r.origin[0], r.origin[1], r.origin[2]), v3(r.direction[0], r.direction[1], r.direction[2]),
-                                             r.t_max, st, h, lc, e);
-        nrays++;
-        if (ANY) out_any[i] = res ? 1 : 0;
-        else { PtxHitRecord o; o.inst_idx = h.inst; o.tri_idx = h.tri; o.t = h.t; o.u = h.u; o.v = h.v; out_hits[i] = o; }
-    }
+    BatchSrc src{rays};
+    BatchSink<ANY> sink{out_hits, out_any};
+    trace_queue<ANY, CNT>(S, st, work, n, src, sink, lc, nrays, e);
     if (e) atomicOr(err, e);
     if (CNT) flush_lane_cnt(dc, lc, nrays, ANY);
 }
@@ -178,64 +190,73 @@ __global__ void k_raygen(SceneDev S, CameraDev cam, PathArrays P, const uint32_t
 }
 
 // ---- extend: Scene::hit for every live path ----------------------------------------
+struct ExtendSrc {
+    const PathArrays& P;
+    const uint32_t* q;
+    PT_DEV void fetch(uint32_t i, V3* o, V3* d, float* tmax) const {
+        const uint32_t p = q[i];
+        const float4 ro = P.ray_o[p], rd = P.ray_d[p];
+        *o = v3(ro.x, ro.y, ro.z); *d = v3(rd.x, rd.y, rd.z); *tmax = ro.w;
+    }
+};
+struct ExtendSink {
+    const PathArrays& P;
+    const uint32_t* q;
+    template <class TV>
+    PT_DEV void store(uint32_t i, const TV& tv) const {
+        const uint32_t p = q[i];
+        P.hit[p] = make_float4(tv.best.t, tv.best.u, tv.best.v, __uint_as_float(tv.best.inst));
+        P.hit_tri[p] = tv.best.tri;
+    }
+};
 template <bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_extend(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    const uint32_t n = ctr->n_active;
     LaneCnt lc = {0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, e = 0;
-    for (;;) {
-        uint32_t chunk = 0;
-        if (threadIdx.x == 0) chunk = atomicAdd(&ctr->w_extend, (uint32_t)TRACE_BLOCK);
-        chunk = __shfl(chunk, 0);
-        if (chunk >= n) break;
-        const uint32_t i = chunk + threadIdx.x;
-        if (i < n) {
-            const uint32_t p = q[i];
-            const float4 ro = P.ray_o[p], rd = P.ray_d[p];
-            Hit h;
-            h.inst = PTX_MISS; h.tri = PTX_MISS; h.t = PT_INF; h.u = 0.0f; h.v = 0.0f;
-            trace_ray<false, CNT>(S, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, st, h, lc, e);
-            nrays++;
-            P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.inst));
-            P.hit_tri[p] = h.tri;
-        }
-    }
+    ExtendSrc src{P, q};
+    ExtendSink sink{P, q};
+    trace_queue<false, CNT>(S, st, &ctr->w_extend, ctr->n_active, src, sink, lc, nrays, e);
     if (e) atomicOr(err, e);
     if (CNT) flush_lane_cnt(dc, lc, nrays, false);
 }
 
 // ---- shadow: Scene::hit_any for the NEE queue ---------------------------------------
+struct ShadowSrc {
+    const SceneDev& S;
+    const PathArrays& P;
+    const uint32_t* qs;
+    PT_DEV void fetch(uint32_t i, V3* o, V3* d, float* tmax) const {
+        const uint32_t entry = qs[i];
+        const uint32_t p = entry >> 1;
+        const float4 so = P.sh_o[p];
+        *o = v3(so.x, so.y, so.z);
+        if ((entry & 1u) == 0u) *d = v3(S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]);
+        else { const float4 sd = P.sh_d[p]; *d = v3(sd.x, sd.y, sd.z); }
+        *tmax = PT_INF;   // every shadow ray of the integrator is Ray::new: infinite
+    }
+};
+struct ShadowSink {
+    const PathArrays& P;
+    const uint32_t* qs;
+    template <class TV>
+    PT_DEV void store(uint32_t i, const TV& tv) const {
+        if (!tv.found) return;   // unoccluded: the pending contribution stands
+        const uint32_t entry = qs[i];
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if ((entry & 1u) == 0u) P.c_sun[entry >> 1] = z; else P.c_sky[entry >> 1] = z;
+    }
+};
 template <bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneDev S, PathArrays P, const uint32_t* qs, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    const uint32_t n = ctr->n_shadow;
     LaneCnt lc = {0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, e = 0;
-    for (;;) {
-        uint32_t chunk = 0;
-        if (threadIdx.x == 0) chunk = atomicAdd(&ctr->w_shadow, (uint32_t)TRACE_BLOCK);
-        chunk = __shfl(chunk, 0);
-        if (chunk >= n) break;
-        const uint32_t i = chunk + threadIdx.x;
-        if (i < n) {
-            const uint32_t entry = qs[i];
-            const uint32_t p = entry >> 1, kind = entry & 1u;
-            const float4 so = P.sh_o[p];
-            V3 d;
-            if (kind == 0u) d = v3(S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]);
-            else { const float4 sd = P.sh_d[p]; d = v3(sd.x, sd.y, sd.z); }
-            Hit h;
-            const bool occluded = trace_ray<true, CNT>(S, v3(so.x, so.y, so.z), d, PT_INF, st, h, lc, e);
-            nrays++;
-            if (occluded) {
-                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (kind == 0u) P.c_sun[p] = z; else P.c_sky[p] = z;
-            }
-        }
-    }
+    ShadowSrc src{S, P, qs};
+    ShadowSink sink{P, qs};
+    trace_queue<true, CNT>(S, st, &ctr->w_shadow, ctr->n_shadow, src, sink, lc, nrays, e);
     if (e) atomicOr(err, e);
     if (CNT) flush_lane_cnt(dc, lc, nrays, true);
 }
@@ -1515,6 +1536,7 @@ int32_t ptx_fb_export_dev(PtxContext* ctx, float* d_sum, float* d_sum_sq, uint32
 int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t mode, PtxHitRecord* out_hits, uint8_t* out_any) {
     REQUIRE_SCENE();
     if (n == 0) return PTX_OK;
+    if (n > 0x7FFFFFFFull) return fail(ctx, PTX_ERR_INVALID, "batch too large (max 2^31-1 rays per call)");
     if (!rays || (mode == PTX_TRACE_CLOSEST && !out_hits) || (mode == PTX_TRACE_ANY && !out_any) || (mode != PTX_TRACE_CLOSEST && mode != PTX_TRACE_ANY))
         return fail(ctx, PTX_ERR_INVALID, "bad trace_batch arguments");
     PtxRay* d_rays = nullptr; void* d_out = nullptr;
@@ -1525,13 +1547,15 @@ int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t
     do {
         if (hipMemcpyAsync(d_rays, rays, n * sizeof(PtxRay), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = fail(ctx, PTX_ERR_HIP, "H2D copy failed"); break; }
         const int grid = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
+        uint32_t* d_work = &ctx->ctrs[MAX_ITERS - 3].w_extend;   // spare counter block as the batch cursor
+        if (hipMemsetAsync(&ctx->ctrs[MAX_ITERS - 3], 0, sizeof(IterCtr), ctx->stream) != hipSuccess) { st = fail(ctx, PTX_ERR_HIP, "memset failed"); break; }
         ScopedEvent* ev = new ScopedEvent(ctx, mode == PTX_TRACE_ANY ? CLS_SHADOW : CLS_EXTEND);
         if (mode == PTX_TRACE_ANY) {
-            if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, ctx->ovf, ctx->d_counters, ctx->d_err);
-            else hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, ctx->ovf, ctx->d_counters, ctx->d_err);
+            if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
+            else hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
         } else {
-            if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, ctx->ovf, ctx->d_counters, ctx->d_err);
-            else hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, ctx->ovf, ctx->d_counters, ctx->d_err);
+            if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
+            else hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
         }
         delete ev;
         if (hipMemcpyAsync(mode == PTX_TRACE_ANY ? (void*)out_any : (void*)out_hits, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { st = fail(ctx, PTX_ERR_HIP, "D2H copy failed"); break; }
