@@ -58,7 +58,7 @@ struct PathArrays {
 struct IterCtr { uint32_t n_active, n_shadow, n_final, w_extend, w_shadow, pad0, pad1, pad2; };
 constexpr uint32_t MAX_ITERS = 4096;
 
-constexpr int TRACE_GRID = 256 * 16;       // persistent waves: 16 per CU
+constexpr int TRACE_GRID = 256 * 20;       // persistent waves: 20 per CU (5 per SIMD: the VGPR and LDS budget)
 constexpr int SHADE_BLOCK = 256;
 
 struct Target {
@@ -131,10 +131,12 @@ template <bool ANY>
 struct BatchSink {
     PtxHitRecord* out_hits;
     uint8_t* out_any;
-    template <class TV>
-    PT_DEV void store(uint32_t i, const TV& tv) const {
-        if (ANY) out_any[i] = tv.found ? 1 : 0;
-        else { PtxHitRecord o; o.inst_idx = tv.best.inst; o.tri_idx = tv.best.tri; o.t = tv.best.t; o.u = tv.best.u; o.v = tv.best.v; out_hits[i] = o; }
+    PT_DEV void hit(uint32_t i, uint32_t inst, uint32_t tri, float t, float u, float v) const {
+        PtxHitRecord o; o.inst_idx = inst; o.tri_idx = tri; o.t = t; o.u = u; o.v = v; out_hits[i] = o;
+    }
+    PT_DEV void done(uint32_t i, bool found) const {
+        if (ANY) out_any[i] = found ? 1 : 0;
+        else if (!found) hit(i, PTX_MISS, PTX_MISS, PT_INF, 0.0f, 0.0f);
     }
 };
 template <bool ANY, bool CNT>
@@ -202,11 +204,13 @@ struct ExtendSrc {
 struct ExtendSink {
     const PathArrays& P;
     const uint32_t* q;
-    template <class TV>
-    PT_DEV void store(uint32_t i, const TV& tv) const {
+    PT_DEV void hit(uint32_t i, uint32_t inst, uint32_t tri, float t, float u, float v) const {
         const uint32_t p = q[i];
-        P.hit[p] = make_float4(tv.best.t, tv.best.u, tv.best.v, __uint_as_float(tv.best.inst));
-        P.hit_tri[p] = tv.best.tri;
+        P.hit[p] = make_float4(t, u, v, __uint_as_float(inst));
+        P.hit_tri[p] = tri;
+    }
+    PT_DEV void done(uint32_t i, bool found) const {
+        if (!found) hit(i, PTX_MISS, PTX_MISS, PT_INF, 0.0f, 0.0f);
     }
 };
 template <bool CNT>
@@ -240,9 +244,9 @@ struct ShadowSrc {
 struct ShadowSink {
     const PathArrays& P;
     const uint32_t* qs;
-    template <class TV>
-    PT_DEV void store(uint32_t i, const TV& tv) const {
-        if (!tv.found) return;   // unoccluded: the pending contribution stands
+    PT_DEV void hit(uint32_t, uint32_t, uint32_t, float, float, float) const {}
+    PT_DEV void done(uint32_t i, bool found) const {
+        if (!found) return;   // unoccluded: the pending contribution stands
         const uint32_t entry = qs[i];
         const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if ((entry & 1u) == 0u) P.c_sun[entry >> 1] = z; else P.c_sky[entry >> 1] = z;
@@ -887,50 +891,67 @@ static void free_pool(std::vector<void*>& pool) {
     pool.clear();
 }
 
-// ---- Bvh8Node[] (256 B, 8 slots) -> NodeRec[] (128 B, <= 4 children, chained) ------------
-static bool repack_bvh(const PtxBvh8& bvh, uint32_t n_prims_expected_max, std::vector<NodeRec>& out, uint32_t* n_records) {
+// ---- Bvh8Node[] (256 B, 8 slots) -> NodeRec[] (128 B, <= 4 children; wider nodes become a chain) ----
+// Returns false on an out-of-range child word or an empty node.  *root_word = record 0 with its child count.
+static bool repack_bvh(const PtxBvh8& bvh, std::vector<NodeRec>& out, uint32_t* n_records, uint32_t* root_word) {
     const size_t first = out.size();
-    std::vector<uint32_t> rec_index(bvh.n_nodes);
+    const uint32_t n = bvh.n_nodes;
+    if (n == 0 || n > NODE_INDEX_MASK / 3) return false;
+    std::vector<uint32_t> rec_index(n), first_count(n);
     uint32_t total = 0;
-    for (uint32_t i = 0; i < bvh.n_nodes; ++i) {
+    for (uint32_t i = 0; i < n; ++i) {
         const int nv = __builtin_popcount(bvh.nodes[i].valid_mask);
+        if (nv == 0) return false;
         rec_index[i] = total;
-        total += nv > 4 ? 2u : 1u;
+        total += nv <= 4 ? 1u : (nv <= 7 ? 2u : 3u);
+        first_count[i] = nv <= 4 ? (uint32_t)nv : 4u;
     }
+    auto as_f = [](uint32_t w) { float f; std::memcpy(&f, &w, 4); return f; };
+    if (first + (size_t)total > NODE_INDEX_MASK) return false;
+    const uint32_t abs0 = (uint32_t)first;   // child words carry absolute record indices
+    auto internal_word = [abs0](uint32_t rec, uint32_t count) { return (abs0 + rec) | ((count - 1u) << NODE_NCHILD_SHIFT); };
     out.resize(first + total);
-    for (uint32_t i = 0; i < bvh.n_nodes; ++i) {
-        const PtxBvh8Node& n = bvh.nodes[i];
-        const int nv = __builtin_popcount(n.valid_mask);
+    const float inf = __builtin_inff();
+    for (uint32_t i = 0; i < n; ++i) {
+        const PtxBvh8Node& nd = bvh.nodes[i];
         int slots[8], ns = 0;
-        for (int s = 0; s < 8; ++s) if (n.valid_mask & (1u << s)) slots[ns++] = s;
-        const int nrec = nv > 4 ? 2 : 1;
-        for (int r = 0; r < nrec; ++r) {
-            NodeRec& rec = out[first + rec_index[i] + r];
-            std::memset(&rec, 0, sizeof(rec));
-            const int begin = r * 4, end = std::min(ns, begin + 4);
-            for (int k = begin; k < end; ++k) {
-                const int s = slots[k];
-                uint32_t word = n.children[s];
+        for (int s = 0; s < 8; ++s) if (nd.valid_mask & (1u << s)) slots[ns++] = s;
+        int done = 0;
+        uint32_t rec = rec_index[i];
+        bool head = true;
+        while (done < ns) {
+            NodeRec& r = out[first + rec];
+            std::memset(&r, 0, sizeof(r));
+            const int left = ns - done;
+            const int real = left <= 4 ? left : 3;            // children of the reference node in this record
+            for (int k = 0; k < real; ++k) {
+                const int s = slots[done + k];
+                uint32_t word = nd.children[s];
                 if (word & LEAF_FLAG) {
                     const uint32_t start = word & PRIM_START_MASK, count = ((word >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
                     if ((uint64_t)start + count > bvh.n_primitive_indices) return false;
                 } else {
-                    if (word >= bvh.n_nodes) return false;
-                    word = rec_index[word];
+                    if (word >= n) return false;
+                    word = internal_word(rec_index[word], first_count[word]);
                 }
-                float wf;
-                std::memcpy(&wf, &word, 4);
-                rec.c[2 * (k - begin)] = make_float4(n.min_x[s], n.min_y[s], n.min_z[s], n.max_x[s]);
-                rec.c[2 * (k - begin) + 1] = make_float4(n.max_y[s], n.max_z[s], wf, 0.0f);
+                r.c[2 * k] = make_float4(nd.min_x[s], nd.min_y[s], nd.min_z[s], nd.max_x[s]);
+                r.c[2 * k + 1] = make_float4(nd.max_y[s], nd.max_z[s], as_f(word), 0.0f);
             }
-            const uint32_t meta = (uint32_t)(end - begin) | ((r + 1 < nrec) ? 8u : 0u) | ((uint32_t)nv << 8);
-            float mf;
-            std::memcpy(&mf, &meta, 4);
-            rec.c[1].w = mf;
+            if (left > 4) {
+                // pseudo child: the rest of the node, unbounded box (t_enter = t_min, always "hit"), placed last
+                const int rest = left - 3;
+                const uint32_t next_count = rest <= 4 ? (uint32_t)rest : 4u;
+                r.c[6] = make_float4(-inf, -inf, -inf, inf);
+                r.c[7] = make_float4(inf, inf, as_f(internal_word(rec + 1u, next_count)), 0.0f);
+            }
+            r.c[1].w = as_f(head ? ((uint32_t)ns | 16u) : 0u);
+            head = false;
+            done += real;
+            rec += 1u;
         }
     }
-    (void)n_prims_expected_max;
     *n_records = total;
+    *root_word = internal_word(0u, first_count[0]);
     return true;
 }
 
@@ -1164,6 +1185,7 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
     REQUIRE_CTX();
     if (!sc || sc->abi_version != PTX_ABI_VERSION) return fail(ctx, PTX_ERR_INVALID, "scene descriptor missing or ABI version mismatch");
     if (sc->n_instances && (!sc->instances || !sc->tlas.nodes)) return fail(ctx, PTX_ERR_INVALID, "instances without a TLAS");
+    if (sc->n_instances > MARK_INST_MASK) return fail(ctx, PTX_ERR_UNSUPPORTED, "more than 2^24 - 1 instances");
     if (!sc->n_materials || !sc->materials) return fail(ctx, PTX_ERR_INVALID, "scene needs at least one material");
     if (!sc->blue_noise_pixel.samples || !sc->blue_noise_lens.samples || sc->blue_noise_pixel.size != sc->blue_noise_lens.size || !sc->blue_noise_pixel.size)
         return fail(ctx, PTX_ERR_INVALID, "blue-noise tables missing");
@@ -1176,9 +1198,10 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
     std::vector<MeshRec> meshes(sc->n_meshes);
     std::vector<float> positions, normals, uvs;
     std::vector<uint32_t> indices;
-    uint32_t nrec = 0;
+    uint32_t nrec = 0, tlas_root_word = 0;
+    std::vector<uint32_t> mesh_root_word(sc->n_meshes, 0u);
     if (sc->n_instances) {
-        if (!repack_bvh(sc->tlas, sc->n_instances, nodes, &nrec)) return fail(ctx, PTX_ERR_INVALID, "TLAS child word out of range");
+        if (!repack_bvh(sc->tlas, nodes, &nrec, &tlas_root_word)) return fail(ctx, PTX_ERR_INVALID, "TLAS is empty, too large or has a child word out of range");
         for (uint32_t i = 0; i < sc->tlas.n_primitive_indices; ++i)
             if (sc->tlas.primitive_indices[i] >= sc->n_instances) return fail(ctx, PTX_ERR_INVALID, "TLAS primitive index out of range");
     }
@@ -1202,9 +1225,8 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
         r.n_triangles = m.n_triangles;
         r.node_base = (uint32_t)nodes.size();
         r.tri_base = (uint32_t)tris.size();
-        if (m.bvh.n_nodes == 0) {   // Bvh8::empty(): traverse_* return None/false
-            NodeRec e; std::memset(&e, 0, sizeof(e)); nodes.push_back(e);
-        } else if (!repack_bvh(m.bvh, m.n_triangles, nodes, &nrec)) return fail(ctx, PTX_ERR_INVALID, "mesh BVH child word out of range");
+        if (r.node_base > NODE_INDEX_MASK) return fail(ctx, PTX_ERR_UNSUPPORTED, "more than 2^29 node records");
+        if (!repack_bvh(m.bvh, nodes, &nrec, &mesh_root_word[mi])) return fail(ctx, PTX_ERR_INVALID, "mesh BVH is empty or has a child word out of range");
         for (uint32_t s = 0; s < m.bvh.n_primitive_indices; ++s) {
             const uint32_t t = m.bvh.primitive_indices[s];
             if (t >= m.n_triangles) return fail(ctx, PTX_ERR_INVALID, "mesh BVH primitive index out of range");
@@ -1228,7 +1250,8 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
         pack_cols(in.inverse_transform, &r.m[0]);
         r.m[3] = make_float4(m.bounds_min[0], m.bounds_min[1], m.bounds_min[2], m.bounds_max[0]);
         float nb, tb;
-        std::memcpy(&nb, &meshes[in.blas_index].node_base, 4);
+        const uint32_t nb_word = mesh_root_word[in.blas_index];
+        std::memcpy(&nb, &nb_word, 4);
         std::memcpy(&tb, &meshes[in.blas_index].tri_base, 4);
         r.m[4] = make_float4(m.bounds_max[1], m.bounds_max[2], nb, tb);
         pack_cols(in.transform, &r.m[5]);
@@ -1269,6 +1292,9 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
 
     auto& pool = ctx->scene_allocs;
     HIPCHK(dev_upload(pool, &S.nodes, nodes)); HIPCHK(dev_upload(pool, &S.tlas_prims, tlas_prims)); HIPCHK(dev_upload(pool, &S.tris, tris));
+    std::vector<InstRec> inst_tlas(tlas_prims.size());
+    for (size_t j = 0; j < tlas_prims.size(); ++j) inst_tlas[j] = inst[tlas_prims[j]];
+    HIPCHK(dev_upload(pool, &S.inst_tlas, inst_tlas));
     HIPCHK(dev_upload(pool, &S.inst, inst)); HIPCHK(dev_upload(pool, &S.inst_shade, inst_shade)); HIPCHK(dev_upload(pool, &S.meshes, meshes));
     HIPCHK(dev_upload(pool, &S.positions, positions)); HIPCHK(dev_upload(pool, &S.normals, normals)); HIPCHK(dev_upload(pool, &S.uvs, uvs));
     HIPCHK(dev_upload(pool, &S.indices, indices)); HIPCHK(dev_upload(pool, &S.materials, materials)); HIPCHK(dev_upload(pool, &S.textures, textures));
@@ -1279,6 +1305,7 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
     for (int k = 0; k < 3; ++k) { S.sun_dir[k] = sc->sun.direction[k]; S.sun_color[k] = sc->sun.color[k]; }
     S.sun_cos_angle = sc->sun.cos_angle; S.sun_pdf = sc->sun.pdf;
     S.n_tlas_nodes = sc->n_instances ? n_tlas_records : 0;
+    S.tlas_root_word = tlas_root_word;
     S.has_sss = has_sss ? 1u : 0u;
     ctx->S = S;
     ctx->has_scene = true;

@@ -9,34 +9,51 @@
 //   TriangleMesh::hit/hit_any    shape/triangle_mesh.rs:192-207
 //   intersect_triangle           shape/triangle_mesh.rs:63-100
 //
-// One lane = one ray.  The reference nests three traversals (closures inside
-// closures); on a 64-wide wave that nesting would idle every lane that is not
-// inside an instance, so the three levels are flattened into ONE state machine
-// whose step is "visit one node record", with one unified stack: TLAS entries
-// stay at the bottom while a lane is inside an instance, mesh entries sit above
-// `base`.  When the mesh level drains, the lane finishes `Instance::hit` and
-// resumes the TLAS record it came from at the slot/primitive after the instance
-// (the box tests of the remaining slots are redone with the current closest_t;
-// a slot that passed with the older, larger closest_t but fails now would have
-// been skipped by the reference's `dist >= closest_t` check anyway, so the
-// visit order and the accepted hits are unchanged).
+// One lane = one ray; a wave is persistent and pulls rays from the queue as
+// lanes finish (one wave-aggregated atomic).
 //
-// A wave is persistent: lanes whose ray has finished pull the next ray from the
-// queue (one wave-aggregated atomic) while their neighbours keep traversing, so
-// long rays do not hold 63 idle lanes hostage.
+// The reference nests three traversals (closures inside closures) and tests a
+// leaf's primitives in the middle of a node's slot loop.  Run as written on a
+// 64-wide wave, every iteration would execute the node test, the triangle
+// loop, the instance entry and the instance exit one after the other, each for
+// the few lanes that need it (measured: 23 % of lanes active per VALU
+// instruction on coherent primary rays, 14 % on bounce rays).  Here the work
+// is cut into four ACTIONS — visit a node record, test one triangle, enter an
+// instance, leave an instance — driven by ONE typed stack per lane.  Each
+// iteration every lane that finished its action pops its next entry (shared
+// code), then the wave runs the action most lanes are waiting for, plus any
+// other action with at least RUN_THRESHOLD lanes waiting; the remaining lanes
+// sit the iteration out.  Each action body loads its own record, so a lane
+// carries no prefetch registers and the kernel fits more waves per SIMD.
+//
+// Order is preserved exactly through the unified stack:
+//   * a node visit pushes its hit INTERNAL children in ascending slot order,
+//     then its hit LEAF children in descending slot order on top, so the leaves
+//     pop first, in ascending slot order, before any deeper node — which is the
+//     reference's "test leaf slots immediately, push internal slots" order;
+//     internal entries pop in descending slot order, as in the reference;
+//   * the reference's per-slot cull `dist >= closest_t` (accel/bvh.rs:344-347)
+//     is applied when an entry is popped.  An internal child that an earlier
+//     leaf of the same node makes cullable is pushed anyway and dropped by the
+//     identical pop-time test (accel/bvh.rs:327-329): same nodes visited;
+//   * entering an instance pushes a three-entry MARKER (world 1/d, world
+//     closest_t, instance id) under the mesh level; popping it is the end of
+//     the mesh traversal.  A TLAS leaf with several primitives re-pushes its
+//     remainder (uncullable, like the reference's inner `for prim_idx` loop)
+//     below the marker before entering the first.
 //
 // Node test: `a < b ? a : b` / `a > b ? a : b` reproduce _mm256_min_ps/_max_ps
 // including their NaN rule (second operand).  NaNs can only come from 0 * inf,
 // i.e. from a ray with a zero direction component or a non-finite origin; when
-// no lane of the wave carries such a ray the test runs on v_min_f32/v_max_f32
-// (v_min3/v_max3), which give the same values for non-NaN inputs at half the
-// VALU cost.
+// no lane in the node action carries such a ray the test runs on
+// v_min_f32/v_max_f32, which give the same values for non-NaN inputs at half
+// the VALU cost.
 //
 // Stack: the first LDS_STACK entries of each lane live in LDS (entry-major,
 // lane-minor: every lane owns one bank column, so divergent stack pointers
 // never conflict); deeper entries spill to a per-lane strip in HBM.  The
 // reference's arrays hold 64 entries per level and panic beyond that; here the
-// same condition raises an error flag.
+// same condition (on internal pushes) raises an error flag.
 #pragma once
 #include "pt_types.h"
 
@@ -44,9 +61,17 @@ namespace ptd {
 
 constexpr int LDS_STACK = 16;
 constexpr int LEVEL_STACK_LIMIT = 64;                 // accel/bvh.rs:320,379
-constexpr int OVF_STACK = 2 * LEVEL_STACK_LIMIT - LDS_STACK;
+// two levels of internal entries + per level: pending leaves (<= 4), TLAS remainder (1), marker (3)
+constexpr int OVF_STACK = 2 * LEVEL_STACK_LIMIT + 16 - LDS_STACK;
 constexpr int TRACE_BLOCK = 64;                       // one wave per block: traversal needs no barrier
 constexpr uint32_t REFILL_MIN_IDLE = 16;              // refill a wave once this many lanes are idle
+#ifndef PT_RUN_THRESHOLD
+#define PT_RUN_THRESHOLD 24
+#endif
+constexpr uint32_t RUN_THRESHOLD = PT_RUN_THRESHOLD;  // a non-majority action also runs with this many lanes waiting
+constexpr uint32_t NEG_INF_BITS = 0xFF800000u;
+constexpr uint32_t MARK_INST_MASK = 0x00FFFFFFu;      // marker word: instance id | MARK_EXACT
+constexpr uint32_t MARK_EXACT = 0x01000000u;
 
 // File-scope LDS array (address space known at every use: plain ds_read/ds_write,
 // no flat pointers into LDS).  Every kernel that traverses gets its own copy.
@@ -56,8 +81,8 @@ struct StackRef {
     uint2* ovf;            // &ovf[0][global_lane], entry stride = ovf_stride
     uint32_t ovf_stride;
 };
-PT_DEV void st_write(const StackRef& s, int i, uint32_t idx, float d) {
-    const uint2 v = make_uint2(idx, __float_as_uint(d));
+PT_DEV void st_write(const StackRef& s, int i, uint32_t word, uint32_t dist_bits) {
+    const uint2 v = make_uint2(word, dist_bits);
     if (i < LDS_STACK) s_stack[i * TRACE_BLOCK + (int)threadIdx.x] = v;
     else s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride] = v;
 }
@@ -65,8 +90,6 @@ PT_DEV uint2 st_read(const StackRef& s, int i) {
     if (i < LDS_STACK) return s_stack[i * TRACE_BLOCK + (int)threadIdx.x];
     return s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride];
 }
-
-struct Hit { uint32_t inst, tri; float t, u, v; };
 
 struct LaneCnt { uint32_t node_visits, node_children, prim_reads, tri_tests, inst_entries, inst_hits; };
 
@@ -112,218 +135,264 @@ PT_DEV bool ray_needs_exact(V3 o, V3 inv) {
     return !(finitef(inv.x) && finitef(inv.y) && finitef(inv.z) && finitef(o.x) && finitef(o.y) && finitef(o.z));
 }
 
-// Per-lane traversal state.  `begin` loads a ray, `step` visits one node record (or leaves an instance),
-// `done` says the ray has finished; ANY rays also finish on the first triangle hit.
+enum : uint32_t { ACT_IDLE = 0, ACT_NODE = 1, ACT_TRI = 2, ACT_ENTER = 3, ACT_EXIT = 4, ACT_POP = 5, ACT_DONE = 6 };
+
+// Per-lane traversal state.  The world ray is not kept while a lane is inside an instance: it is re-read from the
+// queue entry when the instance is left; the closest hit is written through the sink when it is accepted.
 template <bool ANY, bool CNT>
 struct Traverser {
-    V3 wo, wd;                 // world ray
     V3 o, d, inv;              // ray of the level being traversed
     float ct;                  // closest_t of that level (ANY: its ray.t_max)
-    float ct_world;            // world closest_t, parked while inside an instance
-    int sp, base;
-    uint32_t node_base, tri_base, cur_inst;
-    uint32_t c_rec, c_kj;      // TLAS continuation: record, (slot << 8 | next primitive of that slot)
-    uint32_t m_tri;            // best hit inside the current instance
-    float m_t, m_u, m_v;
-    Hit best;
-    bool in_mesh, found, exact, finished;
+    int sp, lim;               // stack pointer; internal pushes fail at sp >= lim (level base + 64)
+    uint32_t tri_base;         // first TriRec of the mesh being traversed
+    uint32_t m_tri;            // best hit inside the current instance (its t is `ct`)
+    float m_u, m_v;
+    uint32_t act;
+    uint32_t pw;               // NODE: child word; TRI: next TriRec; ENTER: TLAS leaf word; EXIT: marker word
+    uint32_t tri_cnt;          // TRI: triangles left in the leaf
+    bool in_mesh, found, exact;
 
-    PT_DEV void begin(const SceneDev& S, const StackRef& st, V3 origin, V3 direction, float tmax) {
-        wo = origin; wd = direction;
+    PT_DEV void begin(const SceneDev& S, V3 origin, V3 direction, float tmax) {
         o = origin; d = direction;
         inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);          // Ray::new (ray.rs:13-21)
         exact = ray_needs_exact(o, inv);
-        ct = tmax; ct_world = tmax;
-        sp = 0; base = 0; node_base = 0; tri_base = 0; cur_inst = 0; c_rec = 0; c_kj = 0;
-        m_tri = PTX_MISS; m_t = 0.0f; m_u = 0.0f; m_v = 0.0f;
-        best.inst = PTX_MISS; best.tri = PTX_MISS; best.t = PT_INF; best.u = 0.0f; best.v = 0.0f;
+        ct = tmax;
+        sp = 0; lim = LEVEL_STACK_LIMIT; tri_base = 0;
+        m_tri = PTX_MISS; m_u = 0.0f; m_v = 0.0f;
         in_mesh = false; found = false;
-        finished = S.n_tlas_nodes == 0;                         // Bvh8::traverse_*: empty => None/false
-        if (!finished) st_write(st, sp++, 0u, 0.0f);            // stack[0] = (root, 0.0)
+        tri_cnt = 0;
+        pw = S.tlas_root_word;
+        // Bvh8::traverse_*: empty => None/false; the root is popped with dist 0.0: culled only if closest_t <= 0
+        // (accel/bvh.rs:322-329)
+        act = (S.n_tlas_nodes == 0 || (!ANY && 0.0f >= ct)) ? ACT_DONE : ACT_NODE;
     }
 
-    // wave_exact: some lane of the wave needs the NaN-exact node test (wave-uniform)
-    PT_DEV void step(const SceneDev& S, const StackRef& st, const bool wave_exact, LaneCnt& lc, uint32_t& err) {
-        const float tmin = RAY_EPSILON;
-        uint32_t rec = 0, j0 = 0;
-        int k0 = 0;
-        bool fresh = false, have = false;
-        if (sp == base) {
-            // ---- mesh level drained (a lane with sp == base at TLAS level is already finished):
-            //      tail of Instance::hit (accel/mod.rs:128-137)
-            if (!ANY && m_tri != PTX_MISS) {
-                if (CNT) lc.inst_hits++;
-                const InstRec& ir = S.inst[cur_inst];
-                const float4 ma = ir.m[5], mb = ir.m[6], mc = ir.m[7];
-                const V3 local_hit_point = o + m_t * d;
-                const V3 world_hit_point = xf_point(ma, mb, mc, local_hit_point);
-                const float t_world = dot(world_hit_point - wo, wd) / dot(wd, wd);
-                if (t_world < ct_world) {                       // traverse_closest accept (accel/bvh.rs:353-357)
-                    ct_world = t_world;
-                    best.inst = cur_inst; best.tri = m_tri; best.t = t_world; best.u = m_u; best.v = m_v;
-                    found = true;
-                }
-            }
-            in_mesh = false;
-            o = wo; d = wd;
-            inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-            exact = ray_needs_exact(o, inv);
-            ct = ct_world;
-            node_base = 0; base = 0;
-            rec = c_rec; k0 = (int)(c_kj >> 8); j0 = c_kj & 0xFFu;
-            have = true;
-        } else {
-            // pop until an entry survives the distance cull (accel/bvh.rs:324-329)
-            while (sp > base) {
-                --sp;
-                const uint2 e = st_read(st, sp);
-                if (ANY || !(__uint_as_float(e.y) >= ct)) { rec = e.x; fresh = true; have = true; break; }
-            }
+    // ---- pop entries until one needs work; sets the next action (accel/bvh.rs:322-329) ---------------
+    PT_DEV void pop(const StackRef& st) {
+        for (;;) {
+            if (sp == 0) { act = ACT_DONE; return; }
+            --sp;
+            const uint2 e = st_read(st, sp);
+            if (!ANY && __uint_as_float(e.y) >= ct) continue;
+            pw = e.x;
+            if (in_mesh) {
+                if (e.y == NEG_INF_BITS) act = ACT_EXIT;       // the marker: mesh level drained
+                else if (e.x & LEAF_FLAG) {
+                    act = ACT_TRI;
+                    pw = tri_base + (e.x & PRIM_START_MASK);
+                    tri_cnt = ((e.x >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
+                } else act = ACT_NODE;
+            } else act = (e.x & LEAF_FLAG) ? ACT_ENTER : ACT_NODE;
+            return;
         }
+    }
 
-        while (have) {
-            const float4* p = reinterpret_cast<const float4*>(&S.nodes[node_base + rec]);
-            float4 c[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) c[i] = p[i];
-            const uint32_t meta = __float_as_uint(c[1].w);
-            const int nchild = (int)(meta & 7u);
-            const bool more = (meta & 8u) != 0;
-            if (CNT && fresh) { lc.node_visits++; lc.node_children += (meta >> 8) & 15u; }
-            // node.intersect(ray, closest_t): all children against the closest_t of this visit
-            float te[4];
-            uint32_t hits = 0;
-            if (wave_exact) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { te[k] = 0.0f; if (k < nchild && box_test<true>(c[2 * k], c[2 * k + 1], o, inv, tmin, ct, &te[k])) hits |= 1u << k; }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { te[k] = 0.0f; if (k < nchild && box_test<false>(c[2 * k], c[2 * k + 1], o, inv, tmin, ct, &te[k])) hits |= 1u << k; }
-            }
-            hits &= (1u << nchild) - 1u;                        // & valid_mask
-            hits &= ~((1u << k0) - 1u);                         // slots before the continuation point are done
-            if (j0 > 0) hits |= 1u << k0;                       // back from an instance: this leaf continues
-            bool entered = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!((hits >> k) & 1u) || entered) continue;
-                const uint32_t word = __float_as_uint(c[2 * k + 1].z);
-                uint32_t jstart = 0;
-                if (k == k0 && j0 > 0) jstart = j0;
-                else if (!ANY && te[k] >= ct) continue;         // accel/bvh.rs:344-347 (closest_t may have shrunk)
-                if (!(word & LEAF_FLAG)) {
-                    if (sp - base >= LEVEL_STACK_LIMIT) { err = 1u; finished = true; found = false; return; }
-                    st_write(st, sp++, word, te[k]);            // accel/bvh.rs:360-363
-                    continue;
-                }
-                const uint32_t start = word & PRIM_START_MASK;
-                const uint32_t count = ((word >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
-                if (in_mesh) {
-                    // ---- leaf of a mesh BVH: intersect_triangle on each primitive, in order
-                    for (uint32_t j = 0; j < count; ++j) {
-                        const TriRec& tr = S.tris[tri_base + start + j];
-                        const float4 ta = tr.a, tb = tr.b, tc = tr.c;
-                        if (CNT) { lc.prim_reads++; lc.tri_tests++; }
-                        const V3 v0 = v3(ta.x, ta.y, ta.z), edge1 = v3(ta.w, tb.x, tb.y), edge2 = v3(tb.z, tb.w, tc.x);
-                        const V3 h = cross(d, edge2);
-                        const float a = dot(edge1, h);
-                        if (fabsf(a) < 1e-8f) continue;
-                        const float f = 1.0f / a;
-                        const V3 s = o - v0;
-                        const float u = f * dot(s, h);
-                        if (!(u >= 0.0f && u <= 1.0f)) continue;
-                        const V3 q = cross(s, edge1);
-                        const float v = f * dot(d, q);
-                        if (v < 0.0f || u + v > 1.0f) continue;
-                        const float t = f * dot(edge2, q);
-                        if (!(t >= tmin && t <= PT_INF)) continue;  // local ray: t_max = +inf
-                        if (ANY) { found = true; finished = true; return; }
-                        if (t < ct) { ct = t; m_tri = __float_as_uint(tc.y); m_t = t; m_u = u; m_v = v; }
-                    }
-                } else {
-                    // ---- leaf of the TLAS: Instance::hit / hit_any on each primitive, in order
-                    for (uint32_t j = jstart; j < count; ++j) {
-                        const uint32_t inst_idx = S.tlas_prims[start + j];
-                        const InstRec& ir = S.inst[inst_idx];
-                        const float4 ia = ir.m[0], ib = ir.m[1], ic = ir.m[2], b0 = ir.m[3], b1 = ir.m[4];
-                        if (CNT) { lc.prim_reads++; lc.inst_entries++; lc.node_visits++; lc.node_children++; }
-                        const V3 lo = xf_point(ia, ib, ic, wo);
-                        const V3 ld = xf_vector(ia, ib, ic, wd);
-                        const V3 linv = v3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
-                        // Blas level: one node, slot 0 = leaf(0,1) boxed by the mesh bounds; t_max = +inf
-                        float tb_enter;
-                        const bool bhit = box_test<true>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
-                        if (!bhit) continue;
-                        if (!ANY && tb_enter >= PT_INF) continue;
-                        if (CNT) lc.prim_reads++;   // the Blas leaf's own primitive index
-                        // descend into the mesh BVH (TriangleMesh::hit: closest_t = local t_max = +inf)
-                        c_rec = rec; c_kj = ((uint32_t)k << 8) | (j + 1u);
-                        in_mesh = true; entered = true;
-                        cur_inst = inst_idx;
-                        ct_world = ct; ct = PT_INF;
-                        o = lo; d = ld; inv = linv;
-                        exact = ray_needs_exact(o, inv);
-                        node_base = __float_as_uint(b1.z); tri_base = __float_as_uint(b1.w);
-                        m_tri = PTX_MISS;
-                        base = sp;
-                        st_write(st, sp++, 0u, 0.0f);
-                        break;
-                    }
-                }
-            }
-            if (entered || !more) break;
-            fresh = false; k0 = 0; j0 = 0; rec += 1u;           // a node with 5-8 children continues in the next record
+    // ---- ACT_NODE: node.intersect + the slot loop's pushes -----------------------------
+    template <bool EXACT>
+    PT_DEV void do_node(const SceneDev& S, const StackRef& st, LaneCnt& lc, uint32_t& err) {
+        const float tmin = RAY_EPSILON;
+        const uint32_t nchild = ((pw >> NODE_NCHILD_SHIFT) & 3u) + 1u;
+        const float4* p = reinterpret_cast<const float4*>(&S.nodes[pw & NODE_INDEX_MASK]);
+        // children 0..2 are read unconditionally (unused slots of a record are zero); the 4th only exists in the
+        // chains built for nodes wider than the reference's builder produces
+        const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3], c0 = p[4], c1 = p[5];
+        float4 d0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d1 = d0;
+        if (nchild > 3u) { d0 = p[6]; d1 = p[7]; }
+        if (CNT) {
+            const uint32_t meta = __float_as_uint(a1.w);
+            lc.node_visits += (meta >> 4) & 1u;
+            lc.node_children += meta & 15u;
         }
-        if (sp == base && !in_mesh) finished = true;
+        float te0, te1, te2, te3 = 0.0f;
+        const bool h0 = box_test<EXACT>(a0, a1, o, inv, tmin, ct, &te0);
+        const bool h1 = box_test<EXACT>(b0, b1, o, inv, tmin, ct, &te1) && nchild > 1u;
+        const bool h2 = box_test<EXACT>(c0, c1, o, inv, tmin, ct, &te2) && nchild > 2u;
+        bool h3 = false;
+        if (nchild > 3u) h3 = box_test<EXACT>(d0, d1, o, inv, tmin, ct, &te3);
+        const uint32_t w0 = __float_as_uint(a1.z), w1 = __float_as_uint(b1.z), w2 = __float_as_uint(c1.z), w3 = __float_as_uint(d1.z);
+        act = ACT_POP;
+        // internal children, ascending slot order (accel/bvh.rs:360-363)
+        const int n_int = (int)(h0 && !(w0 & LEAF_FLAG)) + (int)(h1 && !(w1 & LEAF_FLAG)) + (int)(h2 && !(w2 & LEAF_FLAG)) + (int)(h3 && !(w3 & LEAF_FLAG));
+        if (sp + n_int > lim) { err = 1u; found = false; act = ACT_DONE; return; }
+        if (h0 && !(w0 & LEAF_FLAG)) st_write(st, sp++, w0, __float_as_uint(te0));
+        if (h1 && !(w1 & LEAF_FLAG)) st_write(st, sp++, w1, __float_as_uint(te1));
+        if (h2 && !(w2 & LEAF_FLAG)) st_write(st, sp++, w2, __float_as_uint(te2));
+        if (h3 && !(w3 & LEAF_FLAG)) st_write(st, sp++, w3, __float_as_uint(te3));
+        // leaf children on top, descending, so that they pop in ascending slot order before any deeper node
+        if (h3 && (w3 & LEAF_FLAG)) st_write(st, sp++, w3, __float_as_uint(te3));
+        if (h2 && (w2 & LEAF_FLAG)) st_write(st, sp++, w2, __float_as_uint(te2));
+        if (h1 && (w1 & LEAF_FLAG)) st_write(st, sp++, w1, __float_as_uint(te1));
+        if (h0 && (w0 & LEAF_FLAG)) st_write(st, sp++, w0, __float_as_uint(te0));
+    }
+
+    // ---- ACT_TRI: intersect_triangle on the next primitive of the leaf ------------------
+    PT_DEV void do_tri(const SceneDev& S, LaneCnt& lc) {
+        const float tmin = RAY_EPSILON;
+        const float4* p = reinterpret_cast<const float4*>(&S.tris[pw]);
+        const float4 ta = p[0], tb = p[1], tc = p[2];
+        if (CNT) { lc.prim_reads++; lc.tri_tests++; }
+        pw += 1u; tri_cnt -= 1u;
+        if (tri_cnt == 0u) act = ACT_POP;
+        bool hit = false;
+        float t = 0.0f, u = 0.0f, v = 0.0f;
+        {
+            const V3 v0 = v3(ta.x, ta.y, ta.z), edge1 = v3(ta.w, tb.x, tb.y), edge2 = v3(tb.z, tb.w, tc.x);
+            const V3 h = cross(d, edge2);
+            const float a = dot(edge1, h);
+            if (!(fabsf(a) < 1e-8f)) {
+                const float f = 1.0f / a;
+                const V3 s = o - v0;
+                u = f * dot(s, h);
+                if (u >= 0.0f && u <= 1.0f) {
+                    const V3 q = cross(s, edge1);
+                    v = f * dot(d, q);
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        t = f * dot(edge2, q);
+                        hit = (t >= tmin && t <= PT_INF);   // local ray: t_max = +inf
+                    }
+                }
+            }
+        }
+        if (hit) {
+            if (ANY) { found = true; act = ACT_DONE; return; }
+            if (t < ct) { ct = t; m_tri = __float_as_uint(tc.y); m_u = u; m_v = v; }
+        }
+    }
+
+    // ---- ACT_ENTER: Instance::hit / hit_any head + the Blas-level box ---------------------
+    PT_DEV void do_enter(const SceneDev& S, const StackRef& st, LaneCnt& lc) {
+        const float tmin = RAY_EPSILON;
+        const uint32_t start = pw & PRIM_START_MASK;
+        const uint32_t count = ((pw >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
+        const float4* p = reinterpret_cast<const float4*>(&S.inst_tlas[start]);
+        const float4 ia = p[0], ib = p[1], ic = p[2], b0 = p[3], b1 = p[4];
+        const uint32_t inst_idx = S.tlas_prims[start];
+        // TLAS leaf: this primitive now, the rest after the instance has been left
+        if (count > 1u) st_write(st, sp++, LEAF_FLAG | ((count - 2u) << PRIM_COUNT_SHIFT) | (start + 1u), NEG_INF_BITS);
+        if (CNT) { lc.prim_reads++; lc.inst_entries++; lc.node_visits++; lc.node_children++; }
+        const V3 lo = xf_point(ia, ib, ic, o);
+        const V3 ld = xf_vector(ia, ib, ic, d);
+        const V3 linv = v3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+        // Blas level: one node, slot 0 = leaf(0,1) boxed by the mesh bounds; t_max = +inf
+        float tb_enter;
+        const bool bhit = box_test<true>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
+        if (!bhit || (!ANY && tb_enter >= PT_INF)) { act = ACT_POP; return; }
+        if (CNT) lc.prim_reads++;   // the Blas leaf's own primitive index
+        // park the world level under a marker and descend into the mesh BVH
+        // (TriangleMesh::hit: closest_t = local t_max = +inf; root popped with dist 0)
+        st_write(st, sp++, __float_as_uint(inv.x), __float_as_uint(inv.y));
+        st_write(st, sp++, __float_as_uint(inv.z), __float_as_uint(ct));
+        st_write(st, sp++, inst_idx | (exact ? MARK_EXACT : 0u), NEG_INF_BITS);
+        in_mesh = true;
+        ct = PT_INF;
+        o = lo; d = ld; inv = linv;
+        exact = ray_needs_exact(o, inv);
+        tri_base = __float_as_uint(b1.w);
+        m_tri = PTX_MISS;
+        lim = sp + LEVEL_STACK_LIMIT;
+        pw = __float_as_uint(b1.z);      // record 0 of the mesh BVH (absolute), child count in the top bits
+        act = ACT_NODE;
+    }
+
+    // ---- ACT_EXIT: tail of Instance::hit (accel/mod.rs:128-137); pw = marker word --------------------
+    template <class Src, class Sink>
+    PT_DEV void do_exit(const SceneDev& S, const StackRef& st, LaneCnt& lc, const Src& src, const Sink& sink, uint32_t my) {
+        const uint32_t cur_inst = pw & MARK_INST_MASK;
+        const uint2 e1 = st_read(st, sp - 1), e0 = st_read(st, sp - 2);
+        sp -= 2;
+        V3 wo, wd;
+        float unused_tmax;
+        src.fetch(my, &wo, &wd, &unused_tmax);
+        float ct_world = __uint_as_float(e1.y);
+        if (!ANY && m_tri != PTX_MISS) {
+            if (CNT) lc.inst_hits++;
+            const float4* p = reinterpret_cast<const float4*>(&S.inst[cur_inst]);
+            const float4 ma = p[5], mb = p[6], mc = p[7];
+            const V3 local_hit_point = o + ct * d;
+            const V3 world_hit_point = xf_point(ma, mb, mc, local_hit_point);
+            const float t_world = dot(world_hit_point - wo, wd) / dot(wd, wd);
+            if (t_world < ct_world) {                               // traverse_closest accept (accel/bvh.rs:353-357)
+                ct_world = t_world;
+                sink.hit(my, cur_inst, m_tri, t_world, m_u, m_v);
+                found = true;
+            }
+        }
+        m_tri = PTX_MISS;
+        in_mesh = false;
+        o = wo; d = wd;
+        inv = v3(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e1.x));
+        exact = (pw & MARK_EXACT) != 0u;
+        ct = ct_world;
+        lim = LEVEL_STACK_LIMIT;
+        act = ACT_POP;
     }
 };
 
-// Wave-persistent driver.  `Src::fetch(i, o, d, tmax)` loads queue entry i; `Sink::store(i, trav)` consumes a
-// finished ray.  `work` is the queue's shared cursor, `n` its length.
+// Wave-persistent driver.  `Src::fetch(i, o, d, tmax)` loads queue entry i; `Sink::hit(i, inst, tri, t, u, v)` records
+// an accepted closest hit (the last call for an entry is its result); `Sink::done(i, found)` ends the entry.
+// `work` is the queue's shared cursor, `n` its length.
 template <bool ANY, bool CNT, class Src, class Sink>
-PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, const uint32_t n, Src& src, Sink& sink,
+PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink,
                         LaneCnt& lc, uint32_t& nrays, uint32_t& err) {
     Traverser<ANY, CNT> tv;
-    tv.finished = true;
-    tv.exact = false;
-    bool active = false;
+    tv.act = ACT_IDLE;
+    tv.exact = false; tv.in_mesh = false; tv.found = false;
+    tv.sp = 0; tv.lim = LEVEL_STACK_LIMIT; tv.pw = 0; tv.tri_cnt = 0; tv.tri_base = 0; tv.m_tri = PTX_MISS; tv.m_u = 0.0f; tv.m_v = 0.0f;
+    tv.ct = 0.0f; tv.o = v3(0.0f, 0.0f, 0.0f); tv.d = tv.o; tv.inv = tv.o;
     uint32_t my = 0;
     bool exhausted = false;   // wave-uniform
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = __ballot(tv.act == ACT_IDLE);
         if (!exhausted && (uint32_t)__popcll(idle) >= REFILL_MIN_IDLE) {
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             const int leader = __ffsll((long long)idle) - 1;
             uint32_t basei = 0;
             if ((int)lane == leader) basei = atomicAdd(work, n_idle);
             basei = __shfl(basei, leader);
-            if (!active) {
+            if (tv.act == ACT_IDLE) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t i = basei + rank;
                 if (i < n) {
                     V3 o, d;
                     float tmax;
                     src.fetch(i, &o, &d, &tmax);
-                    tv.begin(S, st, o, d, tmax);
+                    tv.begin(S, o, d, tmax);
                     my = i;
-                    active = true;
                     nrays++;
                 }
             }
             if (basei + n_idle >= n) exhausted = true;
         }
-        // retire rays that are done (an empty TLAS finishes inside begin)
-        if (active && tv.finished) { sink.store(my, tv); active = false; }
-        const unsigned long long live = __ballot(active);
-        if (live == 0ull) {
+        if (tv.act == ACT_POP) tv.pop(st);
+        if (tv.act == ACT_DONE) { sink.done(my, tv.found); tv.act = ACT_IDLE; }
+
+        // vote: the action most lanes are waiting for runs, and so does any other with RUN_THRESHOLD lanes waiting
+        const uint32_t cn = (uint32_t)__popcll(__ballot(tv.act == ACT_NODE));
+        const uint32_t ctn = (uint32_t)__popcll(__ballot(tv.act == ACT_TRI));
+        const uint32_t ce = (uint32_t)__popcll(__ballot(tv.act == ACT_ENTER));
+        const uint32_t cx = (uint32_t)__popcll(__ballot(tv.act == ACT_EXIT));
+        const uint32_t a = cn > ctn ? cn : ctn, b = ce > cx ? ce : cx;
+        const uint32_t mx = a > b ? a : b;
+        if (mx == 0u) {
             if (exhausted) break;
             continue;
         }
-        const bool wave_exact = __ballot(active && tv.exact) != 0ull;
-        if (active) {
-            tv.step(S, st, wave_exact, lc, err);
-            if (tv.finished) { sink.store(my, tv); active = false; }
+        if (cx == mx || cx >= RUN_THRESHOLD) {
+            if (tv.act == ACT_EXIT) tv.do_exit(S, st, lc, src, sink, my);
+        }
+        if (ce == mx || ce >= RUN_THRESHOLD) {
+            if (tv.act == ACT_ENTER) tv.do_enter(S, st, lc);
+        }
+        if (ctn == mx || ctn >= RUN_THRESHOLD) {
+            if (tv.act == ACT_TRI) tv.do_tri(S, lc);
+        }
+        if (cn == mx || cn >= RUN_THRESHOLD) {
+            const bool wave_exact = __ballot(tv.act == ACT_NODE && tv.exact) != 0ull;
+            if (tv.act == ACT_NODE) {
+                if (wave_exact) tv.template do_node<true>(S, st, lc, err);
+                else tv.template do_node<false>(S, st, lc, err);
+            }
         }
     }
 }

@@ -14,14 +14,23 @@ namespace ptd {
 //   c[2k+1] = (max.y, max.z, child_word, meta)
 // child_word: bit31 = leaf; leaf = 1<<31 | (count-1)<<24 | prim_start (start
 // relative to the owning BVH's leaf array, as in the reference); internal =
-// record index relative to the owning BVH's first record.
-// meta (child 0 only): bits 0-2 = number of children in this record (1..4),
-// bit 3 = the node continues in the next record (a host that really fills
-// 5-8 slots), bits 8-11 = popcount(valid_mask) of the whole node (counters).
+// (children_in_target_record - 1) << 29 | ABSOLUTE record index in
+// SceneDev::nodes (mesh BVHs are stored once, so the index can be baked at
+// upload) — the parent says how many children the child record holds.
+// meta (child 0 only, counters): bits 0-3 = popcount(valid_mask) of the
+// reference node, bit 4 = this record starts a reference node.
+// A reference node with 5-8 valid slots (a host with a true 8-wide collapse;
+// the reference's own builder never fills more than 3) becomes a chain
+// [c0 c1 c2 P] -> P = [c3 c4 c5 P'] -> ...: P is a pseudo child with an
+// unbounded box placed LAST, so it pops first, its leaves are tested right
+// after c0..c2's and its internal children end up above theirs — the slot
+// order of the original node.
 struct NodeRec { float4 c[8]; };
 static_assert(sizeof(NodeRec) == 128, "node record must be one 128-byte line");
 
 constexpr uint32_t LEAF_FLAG = 0x80000000u;
+constexpr uint32_t NODE_NCHILD_SHIFT = 29;
+constexpr uint32_t NODE_INDEX_MASK = (1u << NODE_NCHILD_SHIFT) - 1u;
 constexpr uint32_t PRIM_START_MASK = 0x00FFFFFFu;
 constexpr uint32_t PRIM_COUNT_SHIFT = 24;
 constexpr uint32_t PRIM_COUNT_MASK = 0x7Fu;
@@ -37,7 +46,7 @@ static_assert(sizeof(TriRec) == 48, "triangle record");
 // ---- instance record: 128 B ---------------------------------------------------
 //   m[0..2] inverse_transform columns packed (x.xyz,y.x | y.yz,z.xy | z.z,w.xyz)
 //   m[3]    (bounds_min.xyz, bounds_max.x)      -- the Blas-level item box
-//   m[4]    (bounds_max.y, bounds_max.z, node_base, tri_base)
+//   m[4]    (bounds_max.y, bounds_max.z, mesh root record | (root children - 1) << 29, tri_base)
 //   m[5..7] transform columns packed like m[0..2] (read only on an accepted hit)
 struct InstRec { float4 m[8]; };
 static_assert(sizeof(InstRec) == 128, "instance record");
@@ -65,7 +74,8 @@ struct SceneDev {
     const NodeRec* nodes;          // TLAS records first, then every mesh BVH
     const uint32_t* tlas_prims;    // TLAS primitive_indices (instance ids)
     const TriRec* tris;
-    const InstRec* inst;
+    const InstRec* inst;           // by instance id
+    const InstRec* inst_tlas;      // the same records in TLAS primitive_indices order (one load fewer per entry)
     const InstShade* inst_shade;
     const MeshRec* meshes;
     const float* positions;
@@ -89,6 +99,7 @@ struct SceneDev {
     const float* bn_lens;
     uint32_t bn_size;
     uint32_t n_tlas_nodes;         // 0 = empty TLAS (Tlas::build with no instances)
+    uint32_t tlas_root_word;       // record 0 | (children - 1) << 29
     uint32_t has_sss;
 };
 

@@ -59,6 +59,15 @@ for p in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         k = short(r["Kernel_Name"])
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[k].add(r["Dispatch_Id"])
+    if "--per-dispatch" in sys.argv:
+        per = defaultdict(dict)
+        for r in csv.DictReader(open(f)):
+            per[(int(r["Dispatch_Id"]), short(r["Kernel_Name"]))][r["Counter_Name"]] = float(r["Counter_Value"])
+        print(f"\n## {os.path.basename(p)} per dispatch")
+        for (d, k), v in sorted(per.items()):
+            if k.startswith("k_"):
+                print(f"{d:5d} {k:26s} " + "  ".join(f"{c}={x:.4g}" for c, x in sorted(v.items())))
+        continue
     print(f"\n## {os.path.basename(p)} (counter sums over all dispatches of the kernel)")
     for k in sorted(agg, key=lambda kk: -sum(agg[kk].values())):
         if not k.startswith("k_"):
