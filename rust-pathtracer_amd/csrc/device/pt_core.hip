@@ -58,8 +58,12 @@ struct PathArrays {
 struct IterCtr { uint32_t n_active, n_shadow, n_final, w_extend, w_shadow, pad0, pad1, pad2; };
 constexpr uint32_t MAX_ITERS = 4096;
 
-constexpr int TRACE_GRID = 256 * 20;       // persistent waves: 20 per CU (5 per SIMD: the VGPR and LDS budget)
+constexpr int TRACE_GRID = 256 * 4 * PT_WAVES_PER_SIMD;   // persistent waves, PT_WAVES_PER_SIMD per SIMD: the VGPR and LDS budget
 constexpr int SHADE_BLOCK = 256;
+// traversal kernels are compiled for PT_WAVES_PER_SIMD resident waves per SIMD (80 VGPRs at 6)
+#ifndef PT_TRACE_ATTR
+#define PT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_SIMD)))
+#endif
 
 struct Target {
     float* out_rgb;        // by pixel (or by slot) *3, overwritten          (render_pass / render_pixels)
@@ -140,7 +144,7 @@ struct BatchSink {
     }
 };
 template <bool ANY, bool CNT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_batch(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
+__global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
                                                              uint8_t* out_any, uint32_t* work, uint2* ovf, DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
     LaneCnt lc = {0, 0, 0, 0, 0, 0};
@@ -214,7 +218,7 @@ struct ExtendSink {
     }
 };
 template <bool CNT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_extend(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
+__global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
     LaneCnt lc = {0, 0, 0, 0, 0, 0};
@@ -253,7 +257,7 @@ struct ShadowSink {
     }
 };
 template <bool CNT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneDev S, PathArrays P, const uint32_t* qs, IterCtr* ctr, uint2* ovf,
+__global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_shadow(SceneDev S, PathArrays P, const uint32_t* qs, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
     LaneCnt lc = {0, 0, 0, 0, 0, 0};

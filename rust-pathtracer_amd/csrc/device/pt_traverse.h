@@ -59,15 +59,40 @@
 
 namespace ptd {
 
-constexpr int LDS_STACK = 16;
+#ifndef PT_LDS_STACK
+#define PT_LDS_STACK 12
+#endif
+#ifndef PT_REFILL_MIN_IDLE
+#define PT_REFILL_MIN_IDLE 16
+#endif
+#ifndef PT_REFILL_MIN_IDLE_ANY
+#define PT_REFILL_MIN_IDLE_ANY 48
+#endif
+#ifndef PT_WAVES_PER_SIMD
+#define PT_WAVES_PER_SIMD 6
+#endif
+constexpr int LDS_STACK = PT_LDS_STACK;
 constexpr int LEVEL_STACK_LIMIT = 64;                 // accel/bvh.rs:320,379
 // two levels of internal entries + per level: pending leaves (<= 4), TLAS remainder (1), marker (3)
 constexpr int OVF_STACK = 2 * LEVEL_STACK_LIMIT + 16 - LDS_STACK;
 constexpr int TRACE_BLOCK = 64;                       // one wave per block: traversal needs no barrier
-constexpr uint32_t REFILL_MIN_IDLE = 16;              // refill a wave once this many lanes are idle
+constexpr uint32_t REFILL_MIN_IDLE = PT_REFILL_MIN_IDLE, REFILL_MIN_IDLE_ANY = PT_REFILL_MIN_IDLE_ANY;   // refill a wave once this many lanes are idle
 #ifndef PT_RUN_THRESHOLD
-#define PT_RUN_THRESHOLD 24
+#define PT_RUN_THRESHOLD 10
 #endif
+#ifndef PT_TH_NODE
+#define PT_TH_NODE PT_RUN_THRESHOLD
+#endif
+#ifndef PT_TH_TRI
+#define PT_TH_TRI PT_RUN_THRESHOLD
+#endif
+#ifndef PT_TH_ENTER
+#define PT_TH_ENTER PT_RUN_THRESHOLD
+#endif
+#ifndef PT_TH_EXIT
+#define PT_TH_EXIT PT_RUN_THRESHOLD
+#endif
+constexpr uint32_t TH_NODE = PT_TH_NODE, TH_TRI = PT_TH_TRI, TH_ENTER = PT_TH_ENTER, TH_EXIT = PT_TH_EXIT;
 constexpr uint32_t RUN_THRESHOLD = PT_RUN_THRESHOLD;  // a non-majority action also runs with this many lanes waiting
 constexpr uint32_t NEG_INF_BITS = 0xFF800000u;
 constexpr uint32_t MARK_INST_MASK = 0x00FFFFFFu;      // marker word: instance id | MARK_EXACT
@@ -87,8 +112,11 @@ PT_DEV void st_write(const StackRef& s, int i, uint32_t word, uint32_t dist_bits
     else s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride] = v;
 }
 PT_DEV uint2 st_read(const StackRef& s, int i) {
-    if (i < LDS_STACK) return s_stack[i * TRACE_BLOCK + (int)threadIdx.x];
-    return s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride];
+    // the LDS read is unconditional (clamped) and the HBM read predicated: a select between the two address
+    // spaces would make the compiler emit one flat load for both
+    uint2 v = s_stack[(i < LDS_STACK ? i : LDS_STACK - 1) * TRACE_BLOCK + (int)threadIdx.x];
+    if (i >= LDS_STACK) v = s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride];
+    return v;
 }
 
 struct LaneCnt { uint32_t node_visits, node_children, prim_reads, tri_tests, inst_entries, inst_hits; };
@@ -211,18 +239,19 @@ struct Traverser {
         if (nchild > 3u) h3 = box_test<EXACT>(d0, d1, o, inv, tmin, ct, &te3);
         const uint32_t w0 = __float_as_uint(a1.z), w1 = __float_as_uint(b1.z), w2 = __float_as_uint(c1.z), w3 = __float_as_uint(d1.z);
         act = ACT_POP;
-        // internal children, ascending slot order (accel/bvh.rs:360-363)
-        const int n_int = (int)(h0 && !(w0 & LEAF_FLAG)) + (int)(h1 && !(w1 & LEAF_FLAG)) + (int)(h2 && !(w2 & LEAF_FLAG)) + (int)(h3 && !(w3 & LEAF_FLAG));
+        // Internal children go on in ascending slot order (accel/bvh.rs:360-363), leaf children on top of them in
+        // descending order, so that the leaves pop first and in ascending slot order.  Every child's final
+        // position follows from the hit masks, so each child is written once.
+        const int i0 = (int)(h0 && !(w0 & LEAF_FLAG)), i1 = (int)(h1 && !(w1 & LEAF_FLAG)), i2 = (int)(h2 && !(w2 & LEAF_FLAG)), i3 = (int)(h3 && !(w3 & LEAF_FLAG));
+        const int l0 = (int)(h0 && (w0 & LEAF_FLAG)), l1 = (int)(h1 && (w1 & LEAF_FLAG)), l2 = (int)(h2 && (w2 & LEAF_FLAG)), l3 = (int)(h3 && (w3 & LEAF_FLAG));
+        const int n_int = i0 + i1 + i2 + i3;
         if (sp + n_int > lim) { err = 1u; found = false; act = ACT_DONE; return; }
-        if (h0 && !(w0 & LEAF_FLAG)) st_write(st, sp++, w0, __float_as_uint(te0));
-        if (h1 && !(w1 & LEAF_FLAG)) st_write(st, sp++, w1, __float_as_uint(te1));
-        if (h2 && !(w2 & LEAF_FLAG)) st_write(st, sp++, w2, __float_as_uint(te2));
-        if (h3 && !(w3 & LEAF_FLAG)) st_write(st, sp++, w3, __float_as_uint(te3));
-        // leaf children on top, descending, so that they pop in ascending slot order before any deeper node
-        if (h3 && (w3 & LEAF_FLAG)) st_write(st, sp++, w3, __float_as_uint(te3));
-        if (h2 && (w2 & LEAF_FLAG)) st_write(st, sp++, w2, __float_as_uint(te2));
-        if (h1 && (w1 & LEAF_FLAG)) st_write(st, sp++, w1, __float_as_uint(te1));
-        if (h0 && (w0 & LEAF_FLAG)) st_write(st, sp++, w0, __float_as_uint(te0));
+        const int lb = sp + n_int;
+        if (h0) st_write(st, l0 ? lb + l3 + l2 + l1 : sp, w0, __float_as_uint(te0));
+        if (h1) st_write(st, l1 ? lb + l3 + l2 : sp + i0, w1, __float_as_uint(te1));
+        if (h2) st_write(st, l2 ? lb + l3 : sp + i0 + i1, w2, __float_as_uint(te2));
+        if (h3) st_write(st, l3 ? lb : sp + i0 + i1 + i2, w3, __float_as_uint(te3));
+        sp = lb + l0 + l1 + l2 + l3;
     }
 
     // ---- ACT_TRI: intersect_triangle on the next primitive of the leaf ------------------
@@ -233,26 +262,20 @@ struct Traverser {
         if (CNT) { lc.prim_reads++; lc.tri_tests++; }
         pw += 1u; tri_cnt -= 1u;
         if (tri_cnt == 0u) act = ACT_POP;
-        bool hit = false;
-        float t = 0.0f, u = 0.0f, v = 0.0f;
-        {
-            const V3 v0 = v3(ta.x, ta.y, ta.z), edge1 = v3(ta.w, tb.x, tb.y), edge2 = v3(tb.z, tb.w, tc.x);
-            const V3 h = cross(d, edge2);
-            const float a = dot(edge1, h);
-            if (!(fabsf(a) < 1e-8f)) {
-                const float f = 1.0f / a;
-                const V3 s = o - v0;
-                u = f * dot(s, h);
-                if (u >= 0.0f && u <= 1.0f) {
-                    const V3 q = cross(s, edge1);
-                    v = f * dot(d, q);
-                    if (!(v < 0.0f || u + v > 1.0f)) {
-                        t = f * dot(edge2, q);
-                        hit = (t >= tmin && t <= PT_INF);   // local ray: t_max = +inf
-                    }
-                }
-            }
-        }
+        // intersect_triangle with its early returns turned into one predicate: the same operations in the same
+        // order, so a lane that reaches the end has the reference's t, u, v bit for bit; a lane the reference
+        // would have returned early from computes values nobody reads
+        const V3 v0 = v3(ta.x, ta.y, ta.z), edge1 = v3(ta.w, tb.x, tb.y), edge2 = v3(tb.z, tb.w, tc.x);
+        const V3 h = cross(d, edge2);
+        const float a = dot(edge1, h);
+        const float f = 1.0f / a;
+        const V3 s = o - v0;
+        const float u = f * dot(s, h);
+        const V3 q = cross(s, edge1);
+        const float v = f * dot(d, q);
+        const float t = f * dot(edge2, q);
+        const bool hit = !(fabsf(a) < 1e-8f) && (u >= 0.0f && u <= 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
+                         (t >= tmin && t <= PT_INF);   // local ray: t_max = +inf
         if (hit) {
             if (ANY) { found = true; act = ACT_DONE; return; }
             if (t < ct) { ct = t; m_tri = __float_as_uint(tc.y); m_u = u; m_v = v; }
@@ -274,8 +297,11 @@ struct Traverser {
         const V3 ld = xf_vector(ia, ib, ic, d);
         const V3 linv = v3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
         // Blas level: one node, slot 0 = leaf(0,1) boxed by the mesh bounds; t_max = +inf
+        const bool lexact = ray_needs_exact(lo, linv);
         float tb_enter;
-        const bool bhit = box_test<true>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
+        bool bhit;
+        if (__ballot(lexact) != 0ull) bhit = box_test<true>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
+        else bhit = box_test<false>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
         if (!bhit || (!ANY && tb_enter >= PT_INF)) { act = ACT_POP; return; }
         if (CNT) lc.prim_reads++;   // the Blas leaf's own primitive index
         // park the world level under a marker and descend into the mesh BVH
@@ -286,7 +312,7 @@ struct Traverser {
         in_mesh = true;
         ct = PT_INF;
         o = lo; d = ld; inv = linv;
-        exact = ray_needs_exact(o, inv);
+        exact = lexact;
         tri_base = __float_as_uint(b1.w);
         m_tri = PTX_MISS;
         lim = sp + LEVEL_STACK_LIMIT;
@@ -340,11 +366,14 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
     tv.sp = 0; tv.lim = LEVEL_STACK_LIMIT; tv.pw = 0; tv.tri_cnt = 0; tv.tri_base = 0; tv.m_tri = PTX_MISS; tv.m_u = 0.0f; tv.m_v = 0.0f;
     tv.ct = 0.0f; tv.o = v3(0.0f, 0.0f, 0.0f); tv.d = tv.o; tv.inv = tv.o;
     uint32_t my = 0;
+    // Idle lanes claim queue entries with one wave-aggregated atomic as soon as REFILL_MIN_IDLE of them have
+    // gathered.  (Claiming a chunk ahead of need was measured and rejected: a launch lasts only ~16 ray lifetimes,
+    // and entries parked in 6144 waves' prefetch slots lengthen its tail by more than the hidden atomic saves.)
     bool exhausted = false;   // wave-uniform
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
         const unsigned long long idle = __ballot(tv.act == ACT_IDLE);
-        if (!exhausted && (uint32_t)__popcll(idle) >= REFILL_MIN_IDLE) {
+        if (!exhausted && (uint32_t)__popcll(idle) >= (ANY ? REFILL_MIN_IDLE_ANY : REFILL_MIN_IDLE)) {
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             const int leader = __ffsll((long long)idle) - 1;
             uint32_t basei = 0;
@@ -378,16 +407,16 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
             if (exhausted) break;
             continue;
         }
-        if (cx == mx || cx >= RUN_THRESHOLD) {
+        if (cx == mx || cx >= TH_EXIT) {
             if (tv.act == ACT_EXIT) tv.do_exit(S, st, lc, src, sink, my);
         }
-        if (ce == mx || ce >= RUN_THRESHOLD) {
+        if (ce == mx || ce >= TH_ENTER) {
             if (tv.act == ACT_ENTER) tv.do_enter(S, st, lc);
         }
-        if (ctn == mx || ctn >= RUN_THRESHOLD) {
+        if (ctn == mx || ctn >= TH_TRI) {
             if (tv.act == ACT_TRI) tv.do_tri(S, lc);
         }
-        if (cn == mx || cn >= RUN_THRESHOLD) {
+        if (cn == mx || cn >= TH_NODE) {
             const bool wave_exact = __ballot(tv.act == ACT_NODE && tv.exact) != 0ull;
             if (tv.act == ACT_NODE) {
                 if (wave_exact) tv.template do_node<true>(S, st, lc, err);

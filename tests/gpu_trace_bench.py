@@ -1,5 +1,6 @@
 """Traversal micro-benchmark (not collected by pytest): k_trace_batch on primary and bounce rays of the bench scene.
 Prints kernel-only time (HIP events on the library stream) and per-ray event counts."""
+import os
 import sys
 import time
 
@@ -11,7 +12,9 @@ import __graft_entry__ as ge  # noqa: E402
 
 pkg = ge.load_package()
 abi = pkg._abi
-name = sys.argv[1] if len(sys.argv) > 1 else "bistro_like"
+if os.environ.get("PT_VARIANT_LIB"):      # experiments: a library built by tools/build_variant.sh
+    pkg.render.DEVICE_LIB_PATH = os.path.abspath(os.environ["PT_VARIANT_LIB"])
+name =sys.argv[1] if len(sys.argv) > 1 else "bistro_like"
 detail = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 w, h = 1920, 1080
 sc = pkg.Scene.procedural(name, 1, detail, 1)
