@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -73,6 +74,7 @@ struct Target {
     float* sum_sq;
     uint32_t* counts;
     uint32_t by_slot;
+    uint32_t defer;        // several samples per pixel in flight: park the clamped radiance in P.rad, k_accumulate_batch adds it in sample order
 };
 
 // ---- wave64 ballot / prefix queue push ------------------------------------------
@@ -159,13 +161,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(Scene
 // ---- ray-gen: render_pixel up to renderer.render (renderloop/parallel.rs:31-56) ----
 __global__ void k_raygen(SceneDev S, CameraDev cam, PathArrays P, const uint32_t* wl_pixel, const uint32_t* wl_sample,
                          const uint32_t* fb_counts, uint32_t uniform_sample, uint32_t n, uint32_t width, uint32_t height,
-                         uint32_t* q, IterCtr* ctr0, uint32_t aov, PtxRay* out_rays) {
+                         uint32_t* q, IterCtr* ctr0, uint32_t aov, PtxRay* out_rays, uint32_t stride) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && ctr0) ctr0->n_active = n;
     if (i >= n) return;
-    const uint32_t pixel = wl_pixel[i];
+    // stride != 0: slots [k*stride, (k+1)*stride) are sample uniform_sample + k of the same `stride` pixels
+    const uint32_t pixel = wl_pixel[stride ? i % stride : i];
     // sample index: explicit list (render_pixels), the pixel's own count (adaptive), or the pass's
-    const uint32_t sample_index = wl_sample ? wl_sample[i] : (fb_counts ? fb_counts[pixel] : uniform_sample);
+    const uint32_t sample_index = wl_sample ? wl_sample[i] : (fb_counts ? fb_counts[pixel] : uniform_sample + (stride ? i / stride : 0u));
     const uint32_t x = pixel % width, y = pixel / width;
     float px, py, lx, ly;
     bluenoise_sample(S.bn_pixel, S.bn_size, x, y, sample_index, &px, &py);
@@ -695,7 +698,8 @@ __global__ void k_finalize(PathArrays P, const uint32_t* q_final, const IterCtr*
             tg.out_albedo[o] = a.x; tg.out_albedo[o + 1] = a.y; tg.out_albedo[o + 2] = a.z;
             tg.out_normal[o] = nn.x; tg.out_normal[o + 1] = nn.y; tg.out_normal[o + 2] = nn.z;
         }
-        if (tg.sum) {
+        if (tg.defer) P.rad[p] = make_float4(c.x, c.y, c.z, ra4.w);
+        else if (tg.sum) {
             // Framebuffer::accumulate / AdaptiveFramebuffer::add_sample (framebuffer.rs:44-50, 110-125)
             const size_t f = (size_t)pixel * 3;
             tg.sum[f] += c.x; tg.sum[f + 1] += c.y; tg.sum[f + 2] += c.z;
@@ -705,6 +709,25 @@ __global__ void k_finalize(PathArrays P, const uint32_t* q_final, const IterCtr*
         written++;
     }
     if (counting) wave_add(&dc->v[C_PIXEL_SAMPLES], written);
+}
+
+// ---- several passes in flight: add each pixel's samples in pass order (main.rs:131-137 / framebuffer.rs:44-50) ----
+__global__ void k_accumulate_batch(PathArrays P, const uint32_t* wl_pixel, uint32_t stride, uint32_t batch, Target tg) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= stride) return;
+    const uint32_t pixel = wl_pixel[slot];
+    const size_t f = (size_t)pixel * 3;
+    float sx = tg.sum[f], sy = tg.sum[f + 1], sz = tg.sum[f + 2];
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (tg.sum_sq) { qx = tg.sum_sq[f]; qy = tg.sum_sq[f + 1]; qz = tg.sum_sq[f + 2]; }
+    for (uint32_t k = 0; k < batch; ++k) {
+        const float4 c = P.rad[(size_t)k * stride + slot];
+        sx += c.x; sy += c.y; sz += c.z;
+        qx += c.x * c.x; qy += c.y * c.y; qz += c.z * c.z;
+    }
+    tg.sum[f] = sx; tg.sum[f + 1] = sy; tg.sum[f + 2] = sz;
+    if (tg.sum_sq) { tg.sum_sq[f] = qx; tg.sum_sq[f + 1] = qy; tg.sum_sq[f + 2] = qz; }
+    tg.counts[pixel] += batch;
 }
 
 // ---- UnshadedRenderer (renderer/unshaded.rs:7-23) after one extend ---------------------
@@ -816,6 +839,7 @@ __global__ void k_debug_math(int fn, const float* x, const float* y, uint64_t n,
 
 // ================================================================ host side =====
 struct PtxContext {
+    uint64_t max_paths_in_flight = 16ull << 20;   // ptx_fb_render_passes traces this many path slots per wavefront batch (PTX_PATHS_IN_FLIGHT)
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -1073,7 +1097,8 @@ static int32_t check_device_error(PtxContext* ctx) {
 
 // Trace n path slots that k_raygen is about to initialise from (wl_pixel, wl_sample | fb counts | uniform).
 static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32_t* wl_sample, const uint32_t* per_pixel_counts,
-                         uint32_t uniform_sample, uint32_t n, uint32_t w, uint32_t h, uint32_t max_bounces, const Target& tg, bool aov) {
+                         uint32_t uniform_sample, uint32_t n, uint32_t w, uint32_t h, uint32_t max_bounces, const Target& tg, bool aov,
+                         uint32_t stride = 0) {
     if (n == 0) return PTX_OK;
     int32_t st = ensure_capacity(ctx, n);
     if (st != PTX_OK) return st;
@@ -1083,7 +1108,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
     {
         ScopedEvent ev(ctx, CLS_RAYGEN);
         hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->cam, ctx->P, wl_pixel, wl_sample,
-                           per_pixel_counts, uniform_sample, n, w, h, ctx->q[0], ctx->ctrs, aov ? 1u : 0u, (PtxRay*)nullptr);
+                           per_pixel_counts, uniform_sample, n, w, h, ctx->q[0], ctx->ctrs, aov ? 1u : 0u, (PtxRay*)nullptr, stride);
     }
     const int trace_grid = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
     const int shade_grid = (int)std::min<uint64_t>(256 * 8, (n + SHADE_BLOCK - 1) / SHADE_BLOCK);
@@ -1156,6 +1181,10 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
     PtxContext* c = new PtxContext();
     c->device = device_index;
     ctx = c;
+    if (const char* e = std::getenv("PTX_PATHS_IN_FLIGHT")) {
+        const unsigned long long v = std::strtoull(e, nullptr, 10);
+        if (v) c->max_paths_in_flight = v;
+    }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * MAX_ITERS));
     HIPCHK(hipMalloc((void**)&c->ovf, sizeof(uint2) * (size_t)TRACE_GRID * TRACE_BLOCK * OVF_STACK));
@@ -1356,7 +1385,7 @@ static int32_t render_to_images(PtxContext* ctx, uint32_t w, uint32_t h, uint32_
         if (n) {
             HIPCHK(hipMemsetAsync(ctx->ctrs, 0, sizeof(IterCtr) * 2, ctx->stream));
             hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->cam, ctx->P, ctx->wl_pixel, (const uint32_t*)nullptr,
-                               (const uint32_t*)nullptr, sample_index, n, w, h, ctx->q[0], ctx->ctrs, 0u, (PtxRay*)nullptr);
+                               (const uint32_t*)nullptr, sample_index, n, w, h, ctx->q[0], ctx->ctrs, 0u, (PtxRay*)nullptr, 0u);
             const int tg = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
             hipLaunchKernelGGL(k_extend<false>, dim3(tg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q[0], ctx->ctrs, ctx->ovf, ctx->d_counters, ctx->d_err);
             hipLaunchKernelGGL(k_unshaded, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->P, n, d_rgb);
@@ -1446,9 +1475,25 @@ int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t co
     if (st != PTX_OK) return st;
     Target tg{};
     tg.sum = ctx->fb_sum; tg.sum_sq = ctx->fb_sum_sq; tg.counts = ctx->fb_counts;
-    for (uint32_t k = 0; k < count; ++k) {
-        st = run_paths(ctx, ctx->wl_pixel, nullptr, nullptr, first_sample + k, ctx->wl_n, ctx->fb_w, ctx->fb_h, max_bounces, tg, false);
-        if (st != PTX_OK) return st;
+    // The passes of this call are independent (each path seeds its own RNG, parallel.rs:31-56), so several are
+    // traced together: the wavefront queues stay long enough to fill the chip, and k_accumulate_batch adds every
+    // pixel's samples in pass order, which keeps the sums bit-identical to one pass at a time.
+    const uint32_t n1 = ctx->wl_n;
+    uint32_t in_flight = n1 ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, ctx->max_paths_in_flight / n1), 64) : 1u;
+    for (uint32_t k = 0; k < count && n1;) {
+        const uint32_t b = std::min(in_flight, count - k);
+        if (b == 1) {
+            st = run_paths(ctx, ctx->wl_pixel, nullptr, nullptr, first_sample + k, n1, ctx->fb_w, ctx->fb_h, max_bounces, tg, false);
+            if (st != PTX_OK) return st;
+        } else {
+            Target deferred = tg;
+            deferred.defer = 1u;
+            st = run_paths(ctx, ctx->wl_pixel, nullptr, nullptr, first_sample + k, n1 * b, ctx->fb_w, ctx->fb_h, max_bounces, deferred, false, n1);
+            if (st != PTX_OK) return st;
+            ScopedEvent ev(ctx, CLS_ACCUM);
+            hipLaunchKernelGGL(k_accumulate_batch, dim3((n1 + 255) / 256), dim3(256), 0, ctx->stream, ctx->P, ctx->wl_pixel, n1, b, tg);
+        }
+        k += b;
     }
     add_primary_count(ctx, (uint64_t)ctx->wl_n * count);
     return PTX_OK;
@@ -1608,7 +1653,7 @@ int32_t ptx_generate_primary_rays(PtxContext* ctx, uint32_t w, uint32_t h, uint3
     PtxRay* d_rays = reinterpret_cast<PtxRay*>(ctx->list_a);
     PathArrays none{};
     hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->cam, none, ident, (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, sample_index, n, w, h, (uint32_t*)nullptr, (IterCtr*)nullptr, 0u, d_rays);
+                       (const uint32_t*)nullptr, sample_index, n, w, h, (uint32_t*)nullptr, (IterCtr*)nullptr, 0u, d_rays, 0u);
     HIPCHK(hipMemcpyAsync(out_rays, d_rays, (size_t)n * sizeof(PtxRay), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return PTX_OK;

@@ -207,6 +207,24 @@ def test_framebuffer_and_adaptive_passes(pkg, loop, oracle_det, scenes):
     assert loop.render_adaptive_pass(sc, cam, pkg.PathTracer(8), gfb, pkg.AdaptiveSamplingConfig(64, 0.001)) == w * h
 
 
+def test_passes_in_flight_do_not_change_the_sums(pkg, loop, scenes, monkeypatch):
+    """ptx_fb_render_passes traces several passes per wavefront batch; the sums must equal one pass at a time (and the
+    oracle's, test above) bit for bit, also when the last batch is short (7 passes as 3 + 3 + 1)."""
+    sc = scenes("glass_test", 1, 1.0)
+    w, h = 48, 40
+    cam = sc.default_camera(w / h)
+    ref = pkg.DeviceFramebuffer(loop, w, h, adaptive=True)
+    ref.render_passes(sc, cam, pkg.PathTracer(8), 2, 7)
+    want = ref.read()
+    for in_flight in (1, 3 * w * h):
+        monkeypatch.setenv("PTX_PATHS_IN_FLIGHT", str(in_flight))
+        other = pkg.HipRenderLoop(0)
+        fb = pkg.DeviceFramebuffer(other, w, h, adaptive=True)
+        fb.render_passes(sc, cam, pkg.PathTracer(8), 2, 7)
+        got = fb.read()
+        assert np.array_equal(want[2], got[2]) and np.array_equal(bits(want[0]), bits(got[0])) and np.array_equal(bits(want[1]), bits(got[1]))
+
+
 def test_tile_partition_sums_to_whole_frame(pkg, loop, scenes):
     """Multi-GPU split (8x8 tiles, tile % world == rank): disjoint, and the sum over ranks is the 1-GPU frame, bit for bit."""
     sc = scenes("sponza_like", 1, 0.05)
