@@ -6,6 +6,8 @@ within the stated tolerance against its `libm` build (what a Rust build would co
   relative difference of image means <= 1e-3 per channel (>= 16 spp, >= 4k pixels) and
   RMSE(gpu, cpu) <= 1.25 x RMSE(cpu, cpu') where cpu' = the oracle's own next-samples image.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -205,6 +207,80 @@ def test_framebuffer_and_adaptive_passes(pkg, loop, oracle_det, scenes):
     gfb.reset()
     gfb.render_passes(sc, cam, pkg.PathTracer(8), 0, 1)
     assert loop.render_adaptive_pass(sc, cam, pkg.PathTracer(8), gfb, pkg.AdaptiveSamplingConfig(64, 0.001)) == w * h
+
+
+def _widen_bvh_in_place(bvh, rng):
+    """Pull internal children's slots up into their parent while the parent stays <= 8 wide, and scatter the valid
+    slots over the 8 positions: nodes a true 8-wide collapse would produce (the reference's own builder stops at 3)."""
+    n = int(bvh.n_nodes)
+    dt = np.dtype([("box", np.float32, (6, 8)), ("children", np.uint32, 8), ("valid", np.uint8), ("pad", np.uint8, 31)])
+    assert dt.itemsize == 256
+    nodes = np.ctypeslib.as_array(C.cast(bvh.nodes, C.POINTER(C.c_uint8)), shape=(n * 256,)).view(dt)
+    widest = 0
+    for i in range(n):
+        slots = [(nodes[i]["box"][:, s].copy(), int(nodes[i]["children"][s])) for s in range(8) if nodes[i]["valid"] >> s & 1]
+        grown = True
+        while grown:
+            grown = False
+            for k, (_, word) in enumerate(slots):
+                if word & 0x80000000 or word <= i:
+                    continue
+                sub = [(nodes[word]["box"][:, s].copy(), int(nodes[word]["children"][s])) for s in range(8) if nodes[word]["valid"] >> s & 1]
+                if len(slots) - 1 + len(sub) <= 8:
+                    slots[k:k + 1] = sub
+                    grown = True
+                    break
+        pos = np.sort(rng.choice(8, size=len(slots), replace=False))
+        nodes[i]["valid"] = 0
+        nodes[i]["box"][:] = 0.0
+        nodes[i]["children"][:] = 0
+        for p, (box, word) in zip(pos, slots):
+            nodes[i]["box"][:, p] = box
+            nodes[i]["children"][p] = word
+            nodes[i]["valid"] |= np.uint8(1 << int(p))
+        widest = max(widest, len(slots))
+    return widest
+
+
+@pytest.mark.parametrize("name,detail,flags", [("sponza_like", 0.05, 1), ("instanced_stress", 0.3, 0)])
+def test_nodes_wider_than_four_children(pkg, oracle_det, name, detail, flags):
+    """Records hold 4 children; a 5-8 wide node becomes a chain whose pseudo child must keep the reference's slot
+    order for leaves and for the LIFO of internal children.  Both sides traverse the same widened BVHs."""
+    rng = np.random.default_rng(7)
+    sc = pkg.Scene.procedural(name, 3, detail, flags)
+    d = sc.desc.contents
+    widest = _widen_bvh_in_place(d.tlas, rng)
+    for m in range(d.n_meshes):
+        widest = max(widest, _widen_bvh_in_place(d.meshes[m].bvh, rng))
+    assert widest == 8
+    w, h = 96, 54
+    cam = sc.default_camera(w / h)
+    loop = pkg.HipRenderLoop(0)
+    osc = oracle_det.scene(sc)
+    rays = loop.primary_rays(sc, cam, w, h, 0)
+    hits = loop.trace_closest(sc, rays)
+    ok = hits["inst_idx"] != pkg._abi.PTX_MISS
+    assert ok.mean() > 0.1
+    o = rays["origin"][ok] + rays["direction"][ok] * hits["t"][ok, None]
+    dirs = rng.normal(size=o.shape).astype(np.float32)
+    bounce = np.zeros(len(o), dtype=pkg._abi.ray_dtype())
+    bounce["origin"], bounce["direction"], bounce["t_max"] = o, dirs, np.inf
+    for batch in (rays, bounce):
+        loop.set_counting(True); loop.reset_counters(); oracle_det.reset_counters()
+        g = loop.trace_closest(sc, batch)
+        c = osc.trace_closest(batch)
+        gc, oc = loop.counters(), oracle_det.counters()
+        loop.set_counting(False)
+        for f in ("inst_idx", "tri_idx"):
+            assert np.array_equal(g[f], c[f]), f
+        for f in ("t", "u", "v"):
+            assert np.array_equal(bits(g[f]), bits(c[f])), f
+        for k in ("node_visits", "node_children", "triangle_tests", "instance_entries", "instance_hits", "prim_index_reads"):
+            assert gc[k] == oc[k], (k, gc[k], oc[k])
+        assert np.array_equal(loop.trace_any(sc, batch), osc.trace_any(batch))
+    img_g = loop.render_pass(sc, cam, pkg.PathTracer(4), w, h, 1)
+    img_c = osc.render_pass(cam, w, h, 1, 4)
+    assert np.array_equal(bits(img_g), bits(img_c))
 
 
 def test_passes_in_flight_do_not_change_the_sums(pkg, loop, scenes, monkeypatch):
