@@ -75,6 +75,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = ge.load_package()
+    if os.environ.get("PT_VARIANT_LIB"):      # kernel experiments only: a library built by tools/build_variant.sh
+        pkg.render.DEVICE_LIB_PATH = os.path.abspath(os.environ["PT_VARIANT_LIB"])
     w, h, spp = args.width, args.height, args.spp
     t0 = time.time()
     scene = pkg.Scene.procedural(args.scene, args.seed, args.detail, args.flags)

@@ -60,7 +60,13 @@ struct IterCtr { uint32_t n_active, n_shadow, n_final, w_extend, w_shadow, pad0,
 constexpr uint32_t MAX_ITERS = 4096;
 
 constexpr int TRACE_GRID = 256 * 4 * PT_WAVES_PER_SIMD;   // persistent waves, PT_WAVES_PER_SIMD per SIMD: the VGPR and LDS budget
-constexpr int SHADE_BLOCK = 256;
+#ifndef PT_SHADE_BLOCK
+#define PT_SHADE_BLOCK 256
+#endif
+constexpr int SHADE_BLOCK = PT_SHADE_BLOCK;
+#ifndef PT_SHADE_ATTR
+#define PT_SHADE_ATTR
+#endif
 // traversal kernels are compiled for PT_WAVES_PER_SIMD resident waves per SIMD (80 VGPRs at 6)
 #ifndef PT_TRACE_ATTR
 #define PT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_SIMD)))
@@ -88,6 +94,11 @@ PT_DEV void queue_push(uint32_t* q, uint32_t* counter, bool pred, uint32_t value
     if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
     base = __shfl(base, leader);
     if (pred) q[base + rank] = value;
+}
+
+// rank of this lane among the set bits of a wave64 ballot
+PT_DEV uint32_t wave_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 PT_DEV void wave_add(unsigned long long* dst, uint32_t v) {
@@ -284,9 +295,11 @@ PT_DEV WalkCtx walk_ctx(const PtxMaterial& m, float scale) {
 }
 
 template <bool CNT>
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, PathArrays P, const uint32_t* q, uint32_t* q_next, uint32_t* q_shadow,
+__global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S, PathArrays P, const uint32_t* q, uint32_t* q_next, uint32_t* q_shadow,
                                                        uint32_t* q_final, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
                                                        DevCounters* dc) {
+    __shared__ uint32_t s_cnt[3][SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base[3];
     const uint32_t n = ctr->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
     ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
@@ -662,11 +675,37 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, PathArrays P,
                 P.rng[p] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
             }
         }
-        // wave64 ballot/prefix compaction into the three queues
-        queue_push(q_shadow, &ctr->n_shadow, active && push_sun, p * 2u);
-        queue_push(q_shadow, &ctr->n_shadow, active && push_sky, p * 2u + 1u);
-        queue_push(q_next, &ctr_next->n_active, active && alive, p);
-        queue_push(q_final, &ctr->n_final, active && !alive, p);
+        // Compaction into the three queues: wave64 ballots, block-level totals through LDS, ONE atomic per queue and
+        // block iteration (every wave bumping the same three counters itself made their L2 atomics the kernel's
+        // bottleneck).  The loop bounds are block-uniform, so every thread reaches the barriers.
+        {
+            const uint32_t wave = threadIdx.x >> 6;
+            const unsigned long long m_sun = __ballot(active && push_sun), m_sky = __ballot(active && push_sky);
+            const unsigned long long m_next = __ballot(active && alive), m_fin = __ballot(active && !alive);
+            const uint32_t n_sun = (uint32_t)__popcll(m_sun), n_sky = (uint32_t)__popcll(m_sky);
+            if ((threadIdx.x & 63u) == 0u) {
+                s_cnt[0][wave] = n_sun + n_sky;
+                s_cnt[1][wave] = (uint32_t)__popcll(m_next);
+                s_cnt[2][wave] = (uint32_t)__popcll(m_fin);
+            }
+            __syncthreads();
+            if (threadIdx.x < 3u) {
+                uint32_t total = 0;
+                for (uint32_t k = 0; k < SHADE_BLOCK / 64; ++k) total += s_cnt[threadIdx.x][k];
+                uint32_t* counter = threadIdx.x == 0u ? &ctr->n_shadow : (threadIdx.x == 1u ? &ctr_next->n_active : &ctr->n_final);
+                s_base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
+            }
+            __syncthreads();
+            uint32_t o_sh = s_base[0], o_nx = s_base[1], o_fi = s_base[2];
+            for (uint32_t k = 0; k < wave; ++k) { o_sh += s_cnt[0][k]; o_nx += s_cnt[1][k]; o_fi += s_cnt[2][k]; }
+            const uint32_t lane_lo = threadIdx.x & 63u;
+            (void)lane_lo;
+            if (active && push_sun) q_shadow[o_sh + wave_rank(m_sun)] = p * 2u;
+            if (active && push_sky) q_shadow[o_sh + n_sun + wave_rank(m_sky)] = p * 2u + 1u;
+            if (active && alive) q_next[o_nx + wave_rank(m_next)] = p;
+            if (active && !alive) q_final[o_fi + wave_rank(m_fin)] = p;
+            __syncthreads();   // s_cnt / s_base are rewritten by the next iteration
+        }
     }
     if (CNT) {
         wave_add(&dc->v[C_HITDATA], sc.hitdata);

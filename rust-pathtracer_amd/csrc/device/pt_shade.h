@@ -28,6 +28,9 @@ PT_DEV Rng rng_new(uint32_t seed) { Rng r; r.state = (uint64_t)seed; r.next_u32(
 // Texture::sample (texture.rs:64-101): wrap-repeat bilinear over f32 RGB texels.
 PT_DEV V3 texture_sample(const TexRec& t, const float* texels, float uvx, float uvy, uint32_t& lookups) {
     if (t.offset == ~0ull) return v3(t.solid[0], t.solid[1], t.solid[2]);
+#ifdef PT_EXP_NO_TEX
+    return v3(0.5f, 0.5f, 0.5f);
+#endif
     lookups++;
     const float u = rem_euclid1(uvx), v = rem_euclid1(uvy);
     const float px = u * (float)t.width - 0.5f, py = v * (float)t.height - 0.5f;
@@ -119,6 +122,9 @@ PT_DEV SkySample sky_sample_direction(const SceneDev& S, float u1, float u2, Sha
         return r;
     }
     const uint32_t W = S.sky_w, H = S.sky_h;
+#ifdef PT_EXP_NO_CDF
+    r.direction = v3(0.0f, 1.0f, 0.0f); r.radiance = v3(1.0f, 1.0f, 1.0f); r.pdf = 1.0f + u1 + u2; return r;
+#endif
     const uint32_t y = cdf_search(S.sky_marginal, H + 1, u1, sc.cdf_probes);
     const float v_lo = S.sky_marginal[y], v_hi = S.sky_marginal[y + 1];
     const float dv = (u1 - v_lo) / (v_hi - v_lo + 1e-10f);
