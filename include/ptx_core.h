@@ -312,6 +312,24 @@ int32_t ptx_fb_read_mean(PtxContext* ctx, float* out_mean);
  * an RCCL all-gather then combines across GPUs).  Not synchronised: ordered
  * on the library stream; call ptx_sync before another stream reads it. */
 int32_t ptx_fb_export_dev(PtxContext* ctx, float* d_sum, float* d_sum_sq, uint32_t* d_counts);
+
+/* One whole frame in one call: the `for sample` loop of `run_benchmark`
+ * (src/main.rs:123-141) and, with `adaptive` non-NULL, the progressive loop of
+ * `App::render_fullres_frame` (raytracer/app.rs:195-236): `spp` uniform passes
+ * (sample indices 0..spp-1), then `render_adaptive_pass` until it selects no
+ * pixel or any pixel has `max_spp` samples (max_spp = 0: no adaptive phase).
+ * Accumulation and variance selection stay on the device; one readback at the
+ * end.  out_mean (width*height*3), out_counts (width*height) and out_stats
+ * may each be NULL. */
+typedef struct PtxFrameStats {
+    uint64_t total_samples;        /* framebuffer.rs:140-142 */
+    uint32_t min_samples, max_samples;
+    uint32_t uniform_passes, adaptive_passes;
+    uint64_t adaptive_samples;     /* sum of the adaptive work-list lengths */
+} PtxFrameStats;
+int32_t ptx_render_frame(PtxContext* ctx, uint32_t width, uint32_t height, uint32_t spp,
+                         uint32_t max_bounces, const PtxAdaptiveConfig* adaptive, uint32_t max_spp,
+                         float* out_mean, uint32_t* out_counts, PtxFrameStats* out_stats);
 int32_t ptx_sync(PtxContext* ctx);
 
 /* ---- parity / measurement --------------------------------------------------- */

@@ -146,6 +146,11 @@ class PtxAdaptiveConfig(C.Structure):
     _fields_ = [("min_samples", c_u32), ("variance_threshold", c_f), ("max_samples_per_pass", c_u64)]
 
 
+class PtxFrameStats(C.Structure):
+    _fields_ = [("total_samples", c_u64), ("min_samples", c_u32), ("max_samples", c_u32),
+                ("uniform_passes", c_u32), ("adaptive_passes", c_u32), ("adaptive_samples", c_u64)]
+
+
 class PtxTimings(C.Structure):
     _fields_ = [
         ("raygen_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double),

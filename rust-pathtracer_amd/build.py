@@ -58,8 +58,20 @@ def build_device(force=False):
     return out
 
 
+def build_bench(force=False):
+    """pt_bench: the C++ host driver with the reference's `--benchmark` entry point (src/main.rs:59-153)."""
+    out = os.path.join(LIB, "pt_bench")
+    src = "csrc/host/pt_bench.cpp"
+    deps = [os.path.join(HERE, src), os.path.join(INC, "ptx_core.h"), os.path.join(INC, "pt_host.h"),
+            os.path.join(LIB, "libpt_host.so"), os.path.join(LIB, "libmi355_pt.so")]
+    if force or _stale(out, deps):
+        _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", f"-I{INC}", src, f"-L{LIB}", "-lpt_host", "-lmi355_pt",
+              "-Wl,-rpath,$ORIGIN", "-o", out])
+    return out
+
+
 def build_all(force=False):
-    return build_host(force), build_device(force)
+    return build_host(force), build_device(force), build_bench(force)
 
 
 if __name__ == "__main__":

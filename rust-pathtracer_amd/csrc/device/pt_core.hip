@@ -1648,6 +1648,38 @@ int32_t ptx_fb_export_dev(PtxContext* ctx, float* d_sum, float* d_sum_sq, uint32
 }
 
 // ---- parity / measurement ------------------------------------------------------------------
+int32_t ptx_render_frame(PtxContext* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_bounces,
+                         const PtxAdaptiveConfig* adaptive, uint32_t max_spp, float* out_mean, uint32_t* out_counts,
+                         PtxFrameStats* out_stats) {
+    REQUIRE_CAMERA();
+    int32_t st = ptx_fb_reset(ctx, width, height, adaptive ? 1 : 0);
+    if (st != PTX_OK) return st;
+    st = ptx_fb_render_passes(ctx, 0, spp, max_bounces);
+    if (st != PTX_OK) return st;
+    PtxFrameStats fs{};
+    fs.uniform_passes = spp;
+    if (adaptive && max_spp) {
+        for (;;) {
+            uint32_t mn = 0, mx = 0; uint64_t total = 0;
+            st = ptx_fb_stats(ctx, &mn, &mx, &total);
+            if (st != PTX_OK) return st;
+            if (mx >= max_spp) break;
+            uint64_t rendered = 0;
+            st = ptx_fb_adaptive_pass(ctx, adaptive, max_bounces, &rendered);
+            if (st != PTX_OK) return st;
+            if (rendered == 0) break;             // app.rs: the frame has converged
+            fs.adaptive_passes++;
+            fs.adaptive_samples += rendered;
+        }
+    }
+    st = ptx_fb_stats(ctx, &fs.min_samples, &fs.max_samples, &fs.total_samples);
+    if (st != PTX_OK) return st;
+    if (out_mean) { st = ptx_fb_read_mean(ctx, out_mean); if (st != PTX_OK) return st; }
+    if (out_counts) { st = ptx_fb_read(ctx, nullptr, nullptr, out_counts); if (st != PTX_OK) return st; }
+    if (out_stats) *out_stats = fs;
+    return check_device_error(ctx);
+}
+
 int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t mode, PtxHitRecord* out_hits, uint8_t* out_any) {
     REQUIRE_SCENE();
     if (n == 0) return PTX_OK;

@@ -22,7 +22,7 @@ EXPORTS = [
     "ptx_fb_reset", "ptx_fb_render_passes", "ptx_fb_adaptive_pass", "ptx_fb_stats", "ptx_fb_read",
     "ptx_fb_read_mean", "ptx_fb_export_dev", "ptx_sync", "ptx_trace_batch", "ptx_generate_primary_rays",
     "ptx_set_counting", "ptx_reset_counters", "ptx_get_counters", "ptx_set_profiling", "ptx_reset_timings",
-    "ptx_get_timings", "ptx_debug_math",
+    "ptx_get_timings", "ptx_debug_math", "ptx_render_frame",
 ]
 
 
@@ -62,6 +62,7 @@ def lib():
     L.ptx_fb_read_mean.argtypes = [vp, vp]
     L.ptx_fb_export_dev.argtypes = [vp, vp, vp, vp]
     L.ptx_sync.argtypes = [vp]
+    L.ptx_render_frame.argtypes = [vp, u32, u32, u32, u32, C.POINTER(abi.PtxAdaptiveConfig), u32, vp, vp, C.POINTER(abi.PtxFrameStats)]
     L.ptx_trace_batch.argtypes = [vp, vp, u64, i32, vp, vp]
     L.ptx_generate_primary_rays.argtypes = [vp, u32, u32, u32, vp]
     L.ptx_set_counting.argtypes = [vp, i32]
@@ -190,6 +191,23 @@ class HipRenderLoop:
         n = C.c_uint64(0)
         self._check(self.L.ptx_fb_adaptive_pass(self._h, C.byref(cfg), renderer.max_bounces, C.byref(n)), "ptx_fb_adaptive_pass")
         return int(n.value)
+
+    # -- one whole frame: run_benchmark's `for sample` loop (main.rs:123-141) / app.rs:195-236 ----
+    def render_frame(self, scene, camera, renderer, width, height, spp, adaptive=None, max_spp=0):
+        """Returns (mean image h x w x 3, counts h x w, stats dict).  The framebuffer the call uses is the context's
+        own; a DeviceFramebuffer bound to this loop is overwritten."""
+        self._bind(scene, camera)
+        mean = np.empty((height, width, 3), dtype=np.float32)
+        counts = np.empty((height, width), dtype=np.uint32)
+        fs = abi.PtxFrameStats()
+        cfg = None
+        if adaptive is not None:
+            mx = adaptive.max_samples_per_pass
+            cfg = abi.PtxAdaptiveConfig(adaptive.min_samples, adaptive.variance_threshold, width * height if mx is None else mx)
+        self._check(self.L.ptx_render_frame(self._h, width, height, spp, renderer.max_bounces,
+                                            C.byref(cfg) if cfg is not None else None, max_spp,
+                                            _p(mean), _p(counts), C.byref(fs)), "ptx_render_frame")
+        return mean, counts, {k: int(getattr(fs, k)) for k, _ in abi.PtxFrameStats._fields_}
 
     # -- Scene::hit / hit_any on a caller's batch (scene.rs:44-50) -----------------
     def trace_closest(self, scene, rays):

@@ -209,6 +209,53 @@ def test_framebuffer_and_adaptive_passes(pkg, loop, oracle_det, scenes):
     assert loop.render_adaptive_pass(sc, cam, pkg.PathTracer(8), gfb, pkg.AdaptiveSamplingConfig(64, 0.001)) == w * h
 
 
+def test_render_frame_is_the_composed_loop(pkg, loop, oracle_det, scenes):
+    """ptx_render_frame = fb_reset + spp uniform passes + adaptive passes until converged or capped, one readback."""
+    sc = scenes("cornell", 1, 1.0)
+    w, h = 64, 36
+    cam = sc.default_camera(w / h)
+    cfg = pkg.AdaptiveSamplingConfig(min_samples=4, variance_threshold=0.05)
+    mean, counts, stats = loop.render_frame(sc, cam, pkg.PathTracer(8), w, h, 5, adaptive=cfg, max_spp=9)
+    ofb = OracleFramebuffer(oracle_det.scene(sc), w, h, True)
+    ofb.render_passes(cam, 0, 5, 8)
+    passes = samples = 0
+    while ofb.read()[2].max() < 9:
+        n = ofb.adaptive_pass(cam, 4, 0.05, w * h, 8)
+        if n == 0:
+            break
+        passes += 1
+        samples += n
+    assert passes >= 2
+    assert stats["uniform_passes"] == 5 and stats["adaptive_passes"] == passes and stats["adaptive_samples"] == samples
+    assert np.array_equal(counts, ofb.read()[2]) and np.array_equal(bits(mean), bits(ofb.mean()))
+    assert stats["total_samples"] == int(counts.sum()) and stats["min_samples"] == int(counts.min()) and stats["max_samples"] == int(counts.max())
+    # the benchmark's form: no adaptive phase, no variance buffer
+    mean16, counts16, st16 = loop.render_frame(sc, cam, pkg.PathTracer(8), w, h, 16)
+    plain = OracleFramebuffer(oracle_det.scene(sc), w, h, False)
+    plain.render_passes(cam, 0, 16, 8)
+    assert (counts16 == 16).all() and st16["adaptive_passes"] == 0 and np.array_equal(bits(mean16), bits(plain.mean()))
+
+
+def test_pt_bench_benchmark_entry_point(pkg, loop, scenes):
+    """The C++ host driver keeps the reference's `--benchmark` entry point and report (src/main.rs:77-152), and its
+    frame is the one the Python mirror renders (same library, same scene, same camera)."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.render.DEVICE_LIB_PATH), "pt_bench")
+    r = subprocess.run([exe, "--benchmark", "cornell"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    for line in ("Benchmark: cornell", "Loading model...", "Building acceleration structure...", "Rendering 16 samples at 640x360...",
+                 "  Sample 4/16:", "  Sample 16/16:", "Results:", "  Build time:", "  Render time:", "  Primary rays: 3.69M",
+                 "  Performance:", "Mprimary/s", "  Samples/sec:"):
+        assert line in out, (line, out)
+    sc = scenes("cornell", 0, 1.0)
+    mean, counts, _ = loop.render_frame(sc, sc.default_camera(640 / 360), pkg.PathTracer(8), 640, 360, 16)
+    got = float(re.search(r"Mean radiance: ([0-9.]+)", out).group(1))
+    assert abs(got - float(mean.astype(np.float64).mean())) < 2e-6
+
+
 def _widen_bvh_in_place(bvh, rng):
     """Pull internal children's slots up into their parent while the parent stays <= 8 wide, and scatter the valid
     slots over the 8 positions: nodes a true 8-wide collapse would produce (the reference's own builder stops at 3)."""
