@@ -13,6 +13,7 @@ Layout
 from . import _abi  # noqa: F401
 from . import build  # noqa: F401
 from . import host  # noqa: F401
+from . import gltf  # noqa: F401
 from . import render  # noqa: F401
 from .host import Camera, Scene, SceneBuilder, default_material  # noqa: F401
 from .render import (AdaptiveSamplingConfig, DeviceFramebuffer, HipRenderLoop,  # noqa: F401

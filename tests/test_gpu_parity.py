@@ -256,6 +256,20 @@ def test_pt_bench_benchmark_entry_point(pkg, loop, scenes):
     assert abs(got - float(mean.astype(np.float64).mean())) < 2e-6
 
 
+def test_gltf_scene_renders_like_the_oracle(pkg, loop, oracle_det, tmp_path):
+    """GLB -> load_gltf -> Scene::new -> render: textured, normal-mapped, transmissive materials from a file."""
+    from gltf_fixture import write_test_glb
+    path = str(tmp_path / "scene.glb")
+    write_test_glb(path)
+    g = pkg.gltf.load_gltf(path)
+    sc = pkg.gltf.build_scene(g)
+    w, h = 80, 45
+    cam = pkg.gltf.camera_for(g, w / h)
+    osc = oracle_det.scene(sc)
+    for s in (0, 3):
+        assert np.array_equal(bits(osc.render_pass(cam, w, h, s, 8)), bits(loop.render_pass(sc, cam, pkg.PathTracer(8), w, h, s)))
+
+
 def _widen_bvh_in_place(bvh, rng):
     """Pull internal children's slots up into their parent while the parent stays <= 8 wide, and scatter the valid
     slots over the 8 positions: nodes a true 8-wide collapse would produce (the reference's own builder stops at 3)."""
