@@ -878,7 +878,7 @@ __global__ void k_debug_math(int fn, const float* x, const float* y, uint64_t n,
 
 // ================================================================ host side =====
 struct PtxContext {
-    uint64_t max_paths_in_flight = 16ull << 20;   // ptx_fb_render_passes traces this many path slots per wavefront batch (PTX_PATHS_IN_FLIGHT)
+    uint64_t max_paths_in_flight = 128ull << 20;  // ptx_fb_render_passes traces up to this many path slots (260 B each: 35 GB of the 288) per wavefront batch (PTX_PATHS_IN_FLIGHT)
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
