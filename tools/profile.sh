@@ -7,7 +7,7 @@ TAG=${1:-r01}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --spp 8 $*"
+ARGS="--steps 1 --warmup 0 --no-cpu-baseline --spp 64 $*"
 run() { # name, then rocprofv3 options
   local name=$1; shift
   timeout -s KILL 420 rocprofv3 "$@" -d "$OUT/$name" --output-format csv -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1
