@@ -1,0 +1,188 @@
+//! FFI declarations for libmi355_pt.so — field for field `include/ptx_core.h` (ABI version 1).
+//! Source only: not compiled in the repository that ships it (no Rust toolchain there).
+#![allow(non_camel_case_types, dead_code)]
+use std::os::raw::c_char;
+
+use crate::raytracer::accel::bvh::Bvh8Node; // #[repr(C, align(64))], 256 B: passes as-is (accel/bvh.rs:86-98)
+
+pub const PTX_ABI_VERSION: u32 = 1;
+pub const PTX_OK: i32 = 0;
+pub const PTX_MISS: u32 = 0xFFFF_FFFF;
+pub const PTX_TRACE_CLOSEST: i32 = 0;
+pub const PTX_TRACE_ANY: i32 = 1;
+
+pub enum PtxContext {}
+
+#[repr(C)]
+pub struct PtxBvh8 {
+    pub nodes: *const Bvh8Node,
+    pub n_nodes: u32,
+    pub primitive_indices: *const u32,
+    pub n_primitive_indices: u32,
+}
+
+#[repr(C)]
+pub struct PtxMesh {
+    pub positions: *const f32, // Vec<Vec3>::as_ptr() as *const f32 (glam scalar Vec3 = 3 x f32)
+    pub n_positions: u32,
+    pub normals: *const f32,
+    pub n_normals: u32,
+    pub uvs: *const f32,
+    pub n_uvs: u32,
+    pub indices: *const u32, // Vec<[u32; 3]>
+    pub n_triangles: u32,
+    pub material_id: u32,
+    pub bvh: PtxBvh8,
+    pub bounds_min: [f32; 3],
+    pub bounds_max: [f32; 3],
+}
+
+#[repr(C)]
+pub struct PtxInstance {
+    pub blas_index: u32,
+    pub transform: [f32; 16], // Mat4::to_cols_array()
+    pub inverse_transform: [f32; 16],
+    pub normal_matrix: [f32; 16],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct PtxMaterial {
+    pub base_color_texture: i32, // Option<u32> -> -1 = None
+    pub metallic_roughness_texture: i32,
+    pub normal_texture: i32,
+    pub emissive_texture: i32,
+    pub base_color_factor: [f32; 4],
+    pub roughness_factor: f32,
+    pub metallic_factor: f32,
+    pub normal_scale: f32,
+    pub emissive_factor: [f32; 3],
+    pub ior: f32,
+    pub transmission: f32,
+    pub subsurface: f32,
+    pub subsurface_radius: [f32; 3],
+    pub subsurface_albedo: [f32; 3],
+    pub subsurface_anisotropy: f32,
+    pub subsurface_entry_tint: [f32; 3],
+    pub subsurface_exit_tint: [f32; 3],
+}
+
+#[repr(C)]
+pub struct PtxTexture {
+    pub width: u32,
+    pub height: u32,
+    pub texels: *const f32, // Texture::Image data; null => SolidColor(solid)
+    pub solid: [f32; 3],
+}
+
+#[repr(C)]
+pub struct PtxSky {
+    pub texture: PtxTexture,
+    pub marginal_cdf: *const f32,     // height + 1
+    pub conditional_cdfs: *const f32, // height * (width + 1)
+    pub width: u32,
+    pub height: u32,
+    pub total_weight: f32,
+    pub rotation: f32,
+}
+
+#[repr(C)]
+pub struct PtxSun {
+    pub enabled: u32,
+    pub direction: [f32; 3],
+    pub color: [f32; 3],
+    pub cos_angle: f32,
+    pub pdf: f32,
+}
+
+#[repr(C)]
+pub struct PtxBlueNoise {
+    pub size: u32,
+    pub samples: *const f32, // size*size Vec2
+}
+
+#[repr(C)]
+pub struct PtxSceneDesc {
+    pub abi_version: u32,
+    pub meshes: *const PtxMesh,
+    pub n_meshes: u32,
+    pub instances: *const PtxInstance,
+    pub n_instances: u32,
+    pub tlas: PtxBvh8,
+    pub materials: *const PtxMaterial,
+    pub n_materials: u32,
+    pub textures: *const PtxTexture,
+    pub n_textures: u32,
+    pub sky: PtxSky,
+    pub sun: PtxSun,
+    pub blue_noise_pixel: PtxBlueNoise,
+    pub blue_noise_lens: PtxBlueNoise,
+}
+
+#[repr(C)]
+pub struct PtxCamera {
+    pub inv_vp_matrix: [f32; 16],
+    pub aperture: f32,
+    pub focus_distance: f32,
+    pub right: [f32; 3],
+    pub up: [f32; 3],
+}
+
+#[repr(C)]
+pub struct PtxRay {
+    pub origin: [f32; 3],
+    pub direction: [f32; 3],
+    pub t_max: f32,
+}
+
+#[repr(C)]
+pub struct PtxHitRecord {
+    pub inst_idx: u32,
+    pub tri_idx: u32,
+    pub t: f32,
+    pub u: f32,
+    pub v: f32,
+}
+
+#[repr(C)]
+pub struct PtxAdaptiveConfig {
+    pub min_samples: u32,
+    pub variance_threshold: f32,
+    pub max_samples_per_pass: u64,
+}
+
+#[repr(C)]
+#[derive(Default)]
+pub struct PtxFrameStats {
+    pub total_samples: u64,
+    pub min_samples: u32,
+    pub max_samples: u32,
+    pub uniform_passes: u32,
+    pub adaptive_passes: u32,
+    pub adaptive_samples: u64,
+}
+
+#[link(name = "mi355_pt")]
+extern "C" {
+    pub fn ptx_create(device_index: i32, out_ctx: *mut *mut PtxContext) -> i32;
+    pub fn ptx_destroy(ctx: *mut PtxContext) -> i32;
+    pub fn ptx_last_error(ctx: *const PtxContext) -> *const c_char;
+    pub fn ptx_upload_scene(ctx: *mut PtxContext, scene: *const PtxSceneDesc) -> i32;
+    pub fn ptx_set_camera(ctx: *mut PtxContext, camera: *const PtxCamera) -> i32;
+    pub fn ptx_set_partition(ctx: *mut PtxContext, rank: u32, world: u32) -> i32;
+    pub fn ptx_render_pass(ctx: *mut PtxContext, w: u32, h: u32, sample_index: u32, max_bounces: u32, out_rgb: *mut f32) -> i32;
+    pub fn ptx_render_first_pass_aov(ctx: *mut PtxContext, w: u32, h: u32, max_bounces: u32, out_rgb: *mut f32,
+                                     out_albedo: *mut f32, out_normal: *mut f32) -> i32;
+    pub fn ptx_render_pixels(ctx: *mut PtxContext, w: u32, h: u32, xys: *const u32, n: u64, max_bounces: u32, out_rgb: *mut f32) -> i32;
+    pub fn ptx_render_pass_unshaded(ctx: *mut PtxContext, w: u32, h: u32, sample_index: u32, out_rgb: *mut f32) -> i32;
+    pub fn ptx_fb_reset(ctx: *mut PtxContext, w: u32, h: u32, adaptive: i32) -> i32;
+    pub fn ptx_fb_render_passes(ctx: *mut PtxContext, first_sample: u32, count: u32, max_bounces: u32) -> i32;
+    pub fn ptx_fb_adaptive_pass(ctx: *mut PtxContext, cfg: *const PtxAdaptiveConfig, max_bounces: u32, out_rendered: *mut u64) -> i32;
+    pub fn ptx_fb_stats(ctx: *mut PtxContext, out_min: *mut u32, out_max: *mut u32, out_total: *mut u64) -> i32;
+    pub fn ptx_fb_read(ctx: *mut PtxContext, out_sum: *mut f32, out_sum_sq: *mut f32, out_counts: *mut u32) -> i32;
+    pub fn ptx_fb_read_mean(ctx: *mut PtxContext, out_mean: *mut f32) -> i32;
+    pub fn ptx_render_frame(ctx: *mut PtxContext, w: u32, h: u32, spp: u32, max_bounces: u32, adaptive: *const PtxAdaptiveConfig,
+                            max_spp: u32, out_mean: *mut f32, out_counts: *mut u32, out_stats: *mut PtxFrameStats) -> i32;
+    pub fn ptx_sync(ctx: *mut PtxContext) -> i32;
+    pub fn ptx_trace_batch(ctx: *mut PtxContext, rays: *const PtxRay, n: u64, mode: i32, out_hits: *mut PtxHitRecord, out_any: *mut u8) -> i32;
+}
