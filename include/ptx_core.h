@@ -308,6 +308,11 @@ int32_t ptx_fb_stats(PtxContext* ctx, uint32_t* out_min, uint32_t* out_max,
 int32_t ptx_fb_read(PtxContext* ctx, float* out_sum, float* out_sum_sq, uint32_t* out_counts);
 /* `to_color_buffer` / `get_averaged` (framebuffer.rs:52-59, 216-228). */
 int32_t ptx_fb_read_mean(PtxContext* ctx, float* out_mean);
+/* `ToneMap::apply_with_exposure` + `linear_to_srgb_u8` (exporter/tonemapping.rs:12-115) over the averaged
+ * framebuffer, on the device: width*height*3 bytes leave the GPU instead of 12 per pixel.  tonemap: 0 None, 1 Aces
+ * (the window's default with exposure 1.5, window.rs:37-39), 2 Reinhard, 3 Agx (the PNG export's, app.rs:272). */
+enum { PTX_TONEMAP_NONE = 0, PTX_TONEMAP_ACES = 1, PTX_TONEMAP_REINHARD = 2, PTX_TONEMAP_AGX = 3 };
+int32_t ptx_fb_tonemap_srgb8(PtxContext* ctx, int32_t tonemap, float exposure, uint8_t* out_rgb8);
 /* Same accumulators into caller-owned DEVICE memory (e.g. a torch tensor that
  * an RCCL all-gather then combines across GPUs).  Not synchronised: ordered
  * on the library stream; call ptx_sync before another stream reads it. */

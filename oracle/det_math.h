@@ -135,6 +135,76 @@ static inline float logf_det(float xf) {
     return (float)(ed * LN2_HI + ((2.0 * s) * p + ed * LN2_LO));
 }
 
+// ---- powf / log2f (tone mapping only: exporter/tonemapping.rs) ------------------------
+// The same ln / exp cores as above, kept in f64 between the two so that x^y is rounded to f32 once.
+static inline double log_f64_core(double x) {          // x finite, > 0
+    uint64_t b = f64_to_bits(x);
+    int64_t e = (int64_t)((b >> 52) & 0x7FF) - 1023;
+    b = (b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m = bits_to_f64(b);
+    if (m > 1.41421356237309514547) { m = m * 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 23.0;
+    p = p * z + 1.0 / 21.0;
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double ed = (double)e;
+    return ed * LN2_HI + ((2.0 * s) * p + ed * LN2_LO);
+}
+static inline double exp_f64_core(double x) {          // |x| < 700
+    const double INV_LN2 = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double MAGIC = 6755399441055744.0;
+    const double t = x * INV_LN2 + MAGIC;
+    const double kd = t - MAGIC;
+    const int64_t k = (int64_t)(int32_t)(uint32_t)(f64_to_bits(t) & 0xFFFFFFFFu);
+    const double r = (x - kd * LN2_HI) - kd * LN2_LO;
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    return p * bits_to_f64((uint64_t)(k + 1023) << 52);
+}
+// x^y for the tone mapper's arguments: y is a positive constant (2.2, 1/2.4); x < 0 (AgX's inverse matrix can
+// produce it) is NaN like libm's non-integer power; 0 -> 0; +inf -> +inf.
+static inline float powf_det(float xf, float yf) {
+    if (xf != xf || yf != yf) return __builtin_nanf("");
+    if (xf < 0.0f) return __builtin_nanf("");
+    if (xf == 0.0f) return 0.0f;
+    if (xf == __builtin_inff()) return xf;
+    const double e = (double)yf * log_f64_core((double)xf);
+    if (e > 89.0) return __builtin_inff();
+    if (e < -104.0) return 0.0f;
+    return (float)exp_f64_core(e);
+}
+static inline float log2f_det(float xf) {
+    if (xf != xf) return xf;
+    if (xf < 0.0f) return __builtin_nanf("");
+    if (xf == 0.0f) return -__builtin_inff();
+    if (xf == __builtin_inff()) return xf;
+    return (float)(log_f64_core((double)xf) * 1.44269504088896338700e+00);
+}
+
 // ---- atan / atan2 / asin ---------------------------------------------------------
 static inline double atan_pos(double z) {  // z >= 0 (may be +inf)
     const double PIO2 = 1.57079632679489655800e+00, PIO6 = 5.23598775598298815659e-01;

@@ -49,6 +49,8 @@ inline float m_exp(float x) { return detm::expf_det(x); }
 inline float m_ln(float x) { return detm::logf_det(x); }
 inline float m_atan2(float y, float x) { return detm::atan2f_det(y, x); }
 inline float m_asin(float x) { return detm::asinf_det(x); }
+inline float m_pow(float x, float y) { return detm::powf_det(x, y); }
+inline float m_log2(float x) { return detm::log2f_det(x); }
 #else
 inline float m_sin(float x) { return ::sinf(x); }
 inline float m_cos(float x) { return ::cosf(x); }
@@ -56,6 +58,8 @@ inline float m_exp(float x) { return ::expf(x); }
 inline float m_ln(float x) { return ::logf(x); }
 inline float m_atan2(float y, float x) { return ::atan2f(y, x); }
 inline float m_asin(float x) { return ::asinf(x); }
+inline float m_pow(float x, float y) { return ::powf(x, y); }
+inline float m_log2(float x) { return ::log2f(x); }
 #endif
 
 // Rust f32::min/max/clamp, powi (compiler-rt __powisf2 / LLVM's expansion:
@@ -1109,6 +1113,61 @@ static void render_pass_impl(const Scene& scene, const PtxCamera& cam, size_t w,
     });
 }
 
+namespace {
+// ------------------------------------------------------------ tone mapping -----
+// exporter/tonemapping.rs:12-115.  mode: 0 None, 1 Aces, 2 Reinhard, 3 Agx.
+inline Vec3 tm_aces(Vec3 c) {                                   // :27-44
+    const Vec3 a0{(c.x * 0.59719f + c.y * 0.35458f) + c.z * 0.04823f,
+                  (c.x * 0.07600f + c.y * 0.90834f) + c.z * 0.01566f,
+                  (c.x * 0.02840f + c.y * 0.13383f) + c.z * 0.83777f};
+    auto rrt = [](float v) {
+        const float a = v * (v + 0.0245786f) - 0.000090537f;
+        const float b = v * (v * 0.983729f + 0.432951f) + 0.238081f;
+        return a / b;
+    };
+    const Vec3 r{rrt(a0.x), rrt(a0.y), rrt(a0.z)};
+    const Vec3 o{(r.x * 1.60475f + r.y * -0.53108f) + r.z * -0.07367f,
+                 (r.x * -0.10208f + r.y * 1.10813f) + r.z * -0.00605f,
+                 (r.x * -0.00327f + r.y * -0.07276f) + r.z * 1.07602f};
+    // glam Vec3::clamp = self.max(min).min(max)
+    return Vec3{f_min(f_max(o.x, 0.0f), 1.0f), f_min(f_max(o.y, 0.0f), 1.0f), f_min(f_max(o.z, 0.0f), 1.0f)};
+}
+inline float tm_agx_contrast(float x) {                         // :50-61, left to right
+    const float x2 = x * x;
+    const float x4 = x2 * x2;
+    return (((((x4 * x2 * 15.5f - x4 * x * 40.14f) + x4 * 31.96f) - x2 * x * 6.868f) + x2 * 0.4298f) + x * 0.1191f) - 0.00232f;
+}
+inline Vec3 tm_agx(Vec3 v) {                                    // :63-99; glam Mat3 * Vec3 = (x_axis*v.x + y_axis*v.y) + z_axis*v.z
+    const float MIN_EV = -12.47393f, MAX_EV = 4.026069f;
+    const Vec3 m{(0.842479062253094f * v.x + 0.0423282422610123f * v.y) + 0.0423756549057051f * v.z,
+                 (0.0784335999999992f * v.x + 0.878468636469772f * v.y) + 0.0784336f * v.z,
+                 (0.0792237451477643f * v.x + 0.0791661274605434f * v.y) + 0.879142973793104f * v.z};
+    auto enc = [&](float c) { return (f_clamp(m_log2(f_max(c, 1e-10f)), MIN_EV, MAX_EV) - MIN_EV) / (MAX_EV - MIN_EV); };
+    const Vec3 e{tm_agx_contrast(enc(m.x)), tm_agx_contrast(enc(m.y)), tm_agx_contrast(enc(m.z))};
+    const Vec3 o{(1.19687900512017f * e.x + -0.0528968517574562f * e.y) + -0.0529716355144438f * e.z,
+                 (-0.0980208811401368f * e.x + 1.15190312990417f * e.y) + -0.0980434501171241f * e.z,
+                 (-0.0990297440797205f * e.x + -0.0989611768448433f * e.y) + 1.15107367264116f * e.z};
+    return Vec3{m_pow(o.x, 2.2f), m_pow(o.y, 2.2f), m_pow(o.z, 2.2f)};
+}
+inline Vec3 tm_apply(int mode, Vec3 c, float exposure) {        // apply_with_exposure :22-24
+    c = Vec3{c.x * exposure, c.y * exposure, c.z * exposure};
+    switch (mode) {
+        case 1: return tm_aces(c);
+        case 2: return Vec3{c.x / (c.x + 1.0f), c.y / (c.y + 1.0f), c.z / (c.z + 1.0f)};
+        case 3: return tm_agx(c);
+        default: return c;
+    }
+}
+inline uint8_t tm_srgb_u8(float c) {                            // linear_to_srgb_u8 :101-115; `as u8` saturates, NaN -> 0
+    c = f_clamp(c, 0.0f, 1.0f);
+    const float s = (c <= 0.0031308f) ? 12.92f * c : 1.055f * m_pow(c, 1.0f / 2.4f) - 0.055f;
+    const float v = s * 255.0f;
+    if (!(v > 0.0f)) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)v;
+}
+}  // namespace
+
 extern "C" {
 
 OrcScene* orc_scene_new(const PtxSceneDesc* desc) {
@@ -1324,8 +1383,23 @@ void orc_math(int fn, const float* x, const float* y, uint64_t n, float* out) {
             case 2: out[i] = m_exp(x[i]); break;
             case 3: out[i] = m_ln(x[i]); break;
             case 4: out[i] = m_atan2(x[i], y[i]); break;
+            case 6: out[i] = m_pow(x[i], y[i]); break;
+            case 7: out[i] = m_log2(x[i]); break;
             default: out[i] = m_asin(x[i]); break;
         }
+    }
+}
+// ToneMap::apply_with_exposure + linear_to_srgb_u8 over n pixels (exporter/tonemapping.rs:22-24, 101-115)
+void orc_tonemap_srgb8(int mode, float exposure, const float* rgb, uint64_t n, uint8_t* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const Vec3 c = tm_apply(mode, Vec3{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]}, exposure);
+        out[3 * i] = tm_srgb_u8(c.x); out[3 * i + 1] = tm_srgb_u8(c.y); out[3 * i + 2] = tm_srgb_u8(c.z);
+    }
+}
+void orc_tonemap(int mode, float exposure, const float* rgb, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const Vec3 c = tm_apply(mode, Vec3{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]}, exposure);
+        out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
     }
 }
 // one path from an explicit ray + seed (trace_inner), for targeted tests

@@ -856,6 +856,65 @@ __global__ void k_mean(const float* sum, const uint32_t* counts, uint32_t n_pixe
     else { const float cf = (float)c; out[f] = sum[f] / cf; out[f + 1] = sum[f + 1] / cf; out[f + 2] = sum[f + 2] / cf; }
 }
 
+// ---- tone mapping + sRGB8 on the device (exporter/tonemapping.rs:12-115) ---------------------
+// mode: 0 None, 1 Aces, 2 Reinhard, 3 Agx.  Cuts the readback from 12 B to 3 B per pixel for display / export.
+PT_DEV V3 tm_aces(V3 c) {
+    const V3 a0 = v3((c.x * 0.59719f + c.y * 0.35458f) + c.z * 0.04823f,
+                     (c.x * 0.07600f + c.y * 0.90834f) + c.z * 0.01566f,
+                     (c.x * 0.02840f + c.y * 0.13383f) + c.z * 0.83777f);
+    const V3 a = a0 * (a0 + splat(0.0245786f)) - splat(0.000090537f);
+    const V3 b = a0 * (a0 * 0.983729f + splat(0.432951f)) + splat(0.238081f);
+    const V3 r = a / b;
+    const V3 o = v3((r.x * 1.60475f + r.y * -0.53108f) + r.z * -0.07367f,
+                    (r.x * -0.10208f + r.y * 1.10813f) + r.z * -0.00605f,
+                    (r.x * -0.00327f + r.y * -0.07276f) + r.z * 1.07602f);
+    return clamp01(o);
+}
+PT_DEV float tm_agx_contrast(float x) {
+    const float x2 = x * x;
+    const float x4 = x2 * x2;
+    return (((((x4 * x2 * 15.5f - x4 * x * 40.14f) + x4 * 31.96f) - x2 * x * 6.868f) + x2 * 0.4298f) + x * 0.1191f) - 0.00232f;
+}
+PT_DEV float tm_agx_encode(float c) {
+    const float MIN_EV = -12.47393f, MAX_EV = 4.026069f;
+    return (f_clamp(log2f_det(f_max(c, 1e-10f)), MIN_EV, MAX_EV) - MIN_EV) / (MAX_EV - MIN_EV);
+}
+PT_DEV V3 tm_agx(V3 v) {
+    const V3 m = v3((0.842479062253094f * v.x + 0.0423282422610123f * v.y) + 0.0423756549057051f * v.z,
+                    (0.0784335999999992f * v.x + 0.878468636469772f * v.y) + 0.0784336f * v.z,
+                    (0.0792237451477643f * v.x + 0.0791661274605434f * v.y) + 0.879142973793104f * v.z);
+    const V3 e = v3(tm_agx_contrast(tm_agx_encode(m.x)), tm_agx_contrast(tm_agx_encode(m.y)), tm_agx_contrast(tm_agx_encode(m.z)));
+    const V3 o = v3((1.19687900512017f * e.x + -0.0528968517574562f * e.y) + -0.0529716355144438f * e.z,
+                    (-0.0980208811401368f * e.x + 1.15190312990417f * e.y) + -0.0980434501171241f * e.z,
+                    (-0.0990297440797205f * e.x + -0.0989611768448433f * e.y) + 1.15107367264116f * e.z);
+    return v3(powf_det(o.x, 2.2f), powf_det(o.y, 2.2f), powf_det(o.z, 2.2f));
+}
+PT_DEV V3 tm_apply(int mode, V3 c, float exposure) {
+    c = c * exposure;
+    if (mode == 1) return tm_aces(c);
+    if (mode == 2) return c / (c + splat(1.0f));
+    if (mode == 3) return tm_agx(c);
+    return c;
+}
+PT_DEV uint32_t tm_srgb_u8(float c) {   // linear_to_srgb_u8; Rust `as u8` saturates and maps NaN to 0
+    c = f_clamp(c, 0.0f, 1.0f);
+    const float s = (c <= 0.0031308f) ? 12.92f * c : 1.055f * powf_det(c, 1.0f / 2.4f) - 0.055f;
+    const float v = s * 255.0f;
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 255.0f) return 255u;
+    return (uint32_t)v;
+}
+__global__ void k_tonemap_srgb8(const float* sum, const uint32_t* counts, uint32_t n_pixels, int mode, float exposure, uint8_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const uint32_t c = counts[i];
+    const size_t f = (size_t)i * 3;
+    V3 mean = splat(0.0f);
+    if (c != 0u) { const float cf = (float)c; mean = v3(sum[f] / cf, sum[f + 1] / cf, sum[f + 2] / cf); }
+    const V3 t = tm_apply(mode, mean, exposure);
+    out[f] = (uint8_t)tm_srgb_u8(t.x); out[f + 1] = (uint8_t)tm_srgb_u8(t.y); out[f + 2] = (uint8_t)tm_srgb_u8(t.z);
+}
+
 // ---- test hook: the kernels' transcendental implementations on a caller's inputs --------
 __global__ void k_debug_math(int fn, const float* x, const float* y, uint64_t n, float* out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -869,6 +928,8 @@ __global__ void k_debug_math(int fn, const float* x, const float* y, uint64_t n,
         case 4: r = d_atan2f(x[i], y[i]); break;
         case 5: r = d_asinf(x[i]); break;
         case 6: { float s, c; d_sincosf(x[i], &s, &c); r = s; break; }
+        case 8: r = powf_det(x[i], y[i]); break;
+        case 9: r = log2f_det(x[i]); break;
         default: { float s, c; d_sincosf(x[i], &s, &c); r = c; break; }
     }
     out[i] = r;
@@ -1634,6 +1695,20 @@ int32_t ptx_fb_read_mean(PtxContext* ctx, float* out_mean) {
     if (st != PTX_OK) return st;
     hipLaunchKernelGGL(k_mean, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, ctx->stream, ctx->fb_sum, ctx->fb_counts, (uint32_t)npx, ctx->img);
     HIPCHK(hipMemcpyAsync(out_mean, ctx->img, npx * 12, hipMemcpyDeviceToHost, ctx->stream));
+    return check_device_error(ctx);
+}
+
+int32_t ptx_fb_tonemap_srgb8(PtxContext* ctx, int32_t tonemap, float exposure, uint8_t* out_rgb8) {
+    REQUIRE_CTX();
+    if (!ctx->fb_sum || !out_rgb8) return fail(ctx, PTX_ERR_INVALID, "no framebuffer or null output");
+    if (tonemap < 0 || tonemap > 3) return fail(ctx, PTX_ERR_INVALID, "tonemap must be 0 (None), 1 (Aces), 2 (Reinhard) or 3 (Agx)");
+    const uint64_t npx = (uint64_t)ctx->fb_w * ctx->fb_h;
+    int32_t st = ensure_images(ctx, npx);
+    if (st != PTX_OK) return st;
+    uint8_t* d_out = reinterpret_cast<uint8_t*>(ctx->img);
+    hipLaunchKernelGGL(k_tonemap_srgb8, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, ctx->stream, ctx->fb_sum, ctx->fb_counts,
+                       (uint32_t)npx, (int)tonemap, exposure, d_out);
+    HIPCHK(hipMemcpyAsync(out_rgb8, d_out, npx * 3, hipMemcpyDeviceToHost, ctx->stream));
     return check_device_error(ctx);
 }
 

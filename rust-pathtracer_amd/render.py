@@ -22,7 +22,7 @@ EXPORTS = [
     "ptx_fb_reset", "ptx_fb_render_passes", "ptx_fb_adaptive_pass", "ptx_fb_stats", "ptx_fb_read",
     "ptx_fb_read_mean", "ptx_fb_export_dev", "ptx_sync", "ptx_trace_batch", "ptx_generate_primary_rays",
     "ptx_set_counting", "ptx_reset_counters", "ptx_get_counters", "ptx_set_profiling", "ptx_reset_timings",
-    "ptx_get_timings", "ptx_debug_math", "ptx_render_frame",
+    "ptx_get_timings", "ptx_debug_math", "ptx_render_frame", "ptx_fb_tonemap_srgb8",
 ]
 
 
@@ -62,6 +62,7 @@ def lib():
     L.ptx_fb_read_mean.argtypes = [vp, vp]
     L.ptx_fb_export_dev.argtypes = [vp, vp, vp, vp]
     L.ptx_sync.argtypes = [vp]
+    L.ptx_fb_tonemap_srgb8.argtypes = [vp, i32, C.c_float, vp]
     L.ptx_render_frame.argtypes = [vp, u32, u32, u32, u32, C.POINTER(abi.PtxAdaptiveConfig), u32, vp, vp, C.POINTER(abi.PtxFrameStats)]
     L.ptx_trace_batch.argtypes = [vp, vp, u64, i32, vp, vp]
     L.ptx_generate_primary_rays.argtypes = [vp, u32, u32, u32, vp]
@@ -236,7 +237,7 @@ class HipRenderLoop:
         x = np.ascontiguousarray(x, dtype=np.float32)
         y = np.ascontiguousarray(np.zeros_like(x) if y is None else y, dtype=np.float32)
         out = np.zeros_like(x)
-        code = {"sin": 0, "cos": 1, "exp": 2, "ln": 3, "atan2": 4, "asin": 5, "sincos_s": 6, "sincos_c": 7}[fn]
+        code = {"sin": 0, "cos": 1, "exp": 2, "ln": 3, "atan2": 4, "asin": 5, "sincos_s": 6, "sincos_c": 7, "pow": 8, "log2": 9}[fn]
         self._check(self.L.ptx_debug_math(self._h, code, _p(x), _p(y), x.size, _p(out)), "ptx_debug_math")
         return out
 
@@ -337,6 +338,13 @@ class DeviceFramebuffer:
         m = np.zeros((self.height, self.width, 3), dtype=np.float32)
         self.loop._check(self.loop.L.ptx_fb_read_mean(self.loop._h, _p(m)), "ptx_fb_read_mean")
         return m
+
+    def to_srgb8(self, tonemap="aces", exposure=1.0):
+        """`ToneMap::apply_with_exposure` + `linear_to_srgb_u8` (exporter/tonemapping.rs) on the device -> (H, W, 3) u8."""
+        code = {"none": 0, "aces": 1, "reinhard": 2, "agx": 3}[tonemap]
+        out = np.zeros((self.height, self.width, 3), dtype=np.uint8)
+        self.loop._check(self.loop.L.ptx_fb_tonemap_srgb8(self.loop._h, code, float(exposure), _p(out)), "ptx_fb_tonemap_srgb8")
+        return out
 
     def export_dev(self, d_sum_ptr, d_sum_sq_ptr, d_counts_ptr):
         """Copy the accumulators into caller-owned device memory (raw pointers, e.g. torch `data_ptr()`)."""

@@ -65,6 +65,8 @@ class Oracle:
         L.orc_sky_sample.argtypes = [vp, vp, vp]
         L.orc_texture_sample.argtypes = [vp, u32, f, f, vp]
         L.orc_math.argtypes = [C.c_int, vp, vp, u64, vp]
+        L.orc_tonemap_srgb8.argtypes = [C.c_int, f, vp, u64, vp]
+        L.orc_tonemap.argtypes = [C.c_int, f, vp, u64, vp]
         L.orc_trace_path.argtypes = [vp, vp, u32, u32, vp]
         assert L.orc_is_det_math() == (1 if kind == "det" else 0)
 
@@ -96,7 +98,20 @@ class Oracle:
         x = np.ascontiguousarray(x, dtype=np.float32)
         y = np.ascontiguousarray(np.zeros_like(x) if y is None else y, dtype=np.float32)
         out = np.zeros_like(x)
-        self.L.orc_math({"sin": 0, "cos": 1, "exp": 2, "ln": 3, "atan2": 4, "asin": 5}[fn], _p(x), _p(y), x.size, _p(out))
+        self.L.orc_math({"sin": 0, "cos": 1, "exp": 2, "ln": 3, "atan2": 4, "asin": 5, "pow": 6, "log2": 7}[fn], _p(x), _p(y), x.size, _p(out))
+        return out
+
+    def tonemap_srgb8(self, rgb, tonemap="aces", exposure=1.0):
+        """ToneMap::apply_with_exposure + linear_to_srgb_u8 (exporter/tonemapping.rs) -> u8 array of rgb's shape."""
+        a = np.ascontiguousarray(rgb, dtype=np.float32)
+        out = np.zeros(a.shape, dtype=np.uint8)
+        self.L.orc_tonemap_srgb8({"none": 0, "aces": 1, "reinhard": 2, "agx": 3}[tonemap], C.c_float(exposure), _p(a), a.size // 3, _p(out))
+        return out
+
+    def tonemap(self, rgb, tonemap="aces", exposure=1.0):
+        a = np.ascontiguousarray(rgb, dtype=np.float32)
+        out = np.zeros_like(a)
+        self.L.orc_tonemap({"none": 0, "aces": 1, "reinhard": 2, "agx": 3}[tonemap], C.c_float(exposure), _p(a), a.size // 3, _p(out))
         return out
 
     def clamp_radiance(self, rgb):

@@ -270,6 +270,25 @@ def test_gltf_scene_renders_like_the_oracle(pkg, loop, oracle_det, tmp_path):
         assert np.array_equal(bits(osc.render_pass(cam, w, h, s, 8)), bits(loop.render_pass(sc, cam, pkg.PathTracer(8), w, h, s)))
 
 
+def test_device_tonemap_srgb8(pkg, loop, oracle_det, scenes):
+    """ptx_fb_tonemap_srgb8: mean -> ToneMap::apply_with_exposure -> linear_to_srgb_u8 on the device, byte for byte
+    the det oracle's (and pow/log2 bit for bit)."""
+    sc = scenes("cornell", 1, 1.0)
+    w, h = 64, 36
+    cam = sc.default_camera(w / h)
+    fb = pkg.DeviceFramebuffer(loop, w, h, adaptive=False)
+    fb.render_passes(sc, cam, pkg.PathTracer(8), 0, 4)
+    mean = fb.to_color_buffer()
+    for mode, exposure in (("none", 1.0), ("aces", 1.5), ("reinhard", 0.7), ("agx", 1.0)):
+        assert np.array_equal(fb.to_srgb8(mode, exposure), oracle_det.tonemap_srgb8(mean, mode, exposure)), mode
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(0, 2, 5000), [0.0, 1.0, -1.0, np.inf]]).astype(np.float32)
+    for y in (2.2, 1.0 / 2.4):
+        yy = np.full_like(x, np.float32(y))
+        assert np.array_equal(bits(loop.debug_math("pow", x, yy)), bits(oracle_det.math("pow", x, yy)))
+    assert np.array_equal(bits(loop.debug_math("log2", x[:5002])), bits(oracle_det.math("log2", x[:5002])))
+
+
 def _widen_bvh_in_place(bvh, rng):
     """Pull internal children's slots up into their parent while the parent stays <= 8 wide, and scatter the valid
     slots over the 8 positions: nodes a true 8-wide collapse would produce (the reference's own builder stops at 3)."""
