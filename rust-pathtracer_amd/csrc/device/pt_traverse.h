@@ -216,16 +216,17 @@ struct Traverser {
     }
 
     // ---- ACT_NODE: node.intersect + the slot loop's pushes -----------------------------
-    template <bool EXACT>
+    // FOUR = false: no lane of this run has a 4-child record (the reference's builder never makes one; they only
+    // come from the chains built for wider nodes), so the fourth child's loads, test and push terms are compiled out.
+    template <bool EXACT, bool FOUR>
     PT_DEV void do_node(const SceneDev& S, const StackRef& st, LaneCnt& lc, uint32_t& err) {
         const float tmin = RAY_EPSILON;
         const uint32_t nchild = ((pw >> NODE_NCHILD_SHIFT) & 3u) + 1u;
         const float4* p = reinterpret_cast<const float4*>(&S.nodes[pw & NODE_INDEX_MASK]);
-        // children 0..2 are read unconditionally (unused slots of a record are zero); the 4th only exists in the
-        // chains built for nodes wider than the reference's builder produces
+        // children 0..2 are read unconditionally (unused slots of a record are zero)
         const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3], c0 = p[4], c1 = p[5];
         float4 d0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d1 = d0;
-        if (nchild > 3u) { d0 = p[6]; d1 = p[7]; }
+        if (FOUR && nchild > 3u) { d0 = p[6]; d1 = p[7]; }
         if (CNT) {
             const uint32_t meta = __float_as_uint(a1.w);
             lc.node_visits += (meta >> 4) & 1u;
@@ -236,21 +237,23 @@ struct Traverser {
         const bool h1 = box_test<EXACT>(b0, b1, o, inv, tmin, ct, &te1) && nchild > 1u;
         const bool h2 = box_test<EXACT>(c0, c1, o, inv, tmin, ct, &te2) && nchild > 2u;
         bool h3 = false;
-        if (nchild > 3u) h3 = box_test<EXACT>(d0, d1, o, inv, tmin, ct, &te3);
+        if (FOUR && nchild > 3u) h3 = box_test<EXACT>(d0, d1, o, inv, tmin, ct, &te3);
         const uint32_t w0 = __float_as_uint(a1.z), w1 = __float_as_uint(b1.z), w2 = __float_as_uint(c1.z), w3 = __float_as_uint(d1.z);
         act = ACT_POP;
         // Internal children go on in ascending slot order (accel/bvh.rs:360-363), leaf children on top of them in
         // descending order, so that the leaves pop first and in ascending slot order.  Every child's final
         // position follows from the hit masks, so each child is written once.
-        const int i0 = (int)(h0 && !(w0 & LEAF_FLAG)), i1 = (int)(h1 && !(w1 & LEAF_FLAG)), i2 = (int)(h2 && !(w2 & LEAF_FLAG)), i3 = (int)(h3 && !(w3 & LEAF_FLAG));
-        const int l0 = (int)(h0 && (w0 & LEAF_FLAG)), l1 = (int)(h1 && (w1 & LEAF_FLAG)), l2 = (int)(h2 && (w2 & LEAF_FLAG)), l3 = (int)(h3 && (w3 & LEAF_FLAG));
+        const int i0 = (int)(h0 && !(w0 & LEAF_FLAG)), i1 = (int)(h1 && !(w1 & LEAF_FLAG)), i2 = (int)(h2 && !(w2 & LEAF_FLAG));
+        const int i3 = FOUR ? (int)(h3 && !(w3 & LEAF_FLAG)) : 0;
+        const int l0 = (int)(h0 && (w0 & LEAF_FLAG)), l1 = (int)(h1 && (w1 & LEAF_FLAG)), l2 = (int)(h2 && (w2 & LEAF_FLAG));
+        const int l3 = FOUR ? (int)(h3 && (w3 & LEAF_FLAG)) : 0;
         const int n_int = i0 + i1 + i2 + i3;
         if (sp + n_int > lim) { err = 1u; found = false; act = ACT_DONE; return; }
         const int lb = sp + n_int;
         if (h0) st_write(st, l0 ? lb + l3 + l2 + l1 : sp, w0, __float_as_uint(te0));
         if (h1) st_write(st, l1 ? lb + l3 + l2 : sp + i0, w1, __float_as_uint(te1));
         if (h2) st_write(st, l2 ? lb + l3 : sp + i0 + i1, w2, __float_as_uint(te2));
-        if (h3) st_write(st, l3 ? lb : sp + i0 + i1 + i2, w3, __float_as_uint(te3));
+        if (FOUR && h3) st_write(st, l3 ? lb : sp + i0 + i1 + i2, w3, __float_as_uint(te3));
         sp = lb + l0 + l1 + l2 + l3;
     }
 
@@ -417,10 +420,13 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
             if (tv.act == ACT_TRI) tv.do_tri(S, lc);
         }
         if (cn == mx || cn >= TH_NODE) {
-            const bool wave_exact = __ballot(tv.act == ACT_NODE && tv.exact) != 0ull;
-            if (tv.act == ACT_NODE) {
-                if (wave_exact) tv.template do_node<true>(S, st, lc, err);
-                else tv.template do_node<false>(S, st, lc, err);
+            // wave-uniform choice of the node-visit variant: x86 NaN rule only if some lane can produce NaNs,
+            // fourth child only if some lane's record has one
+            const bool is_node = tv.act == ACT_NODE;
+            const bool wave_special = __ballot(is_node && (tv.exact || (tv.pw >> NODE_NCHILD_SHIFT) == 3u)) != 0ull;
+            if (is_node) {
+                if (wave_special) tv.template do_node<true, true>(S, st, lc, err);
+                else tv.template do_node<false, false>(S, st, lc, err);
             }
         }
     }
