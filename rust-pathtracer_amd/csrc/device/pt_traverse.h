@@ -112,10 +112,16 @@ PT_DEV void st_write(const StackRef& s, int i, uint32_t word, uint32_t dist_bits
     else s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride] = v;
 }
 PT_DEV uint2 st_read(const StackRef& s, int i) {
-    // the LDS read is unconditional (clamped) and the HBM read predicated: a select between the two address
-    // spaces would make the compiler emit one flat load for both
-    uint2 v = s_stack[(i < LDS_STACK ? i : LDS_STACK - 1) * TRACE_BLOCK + (int)threadIdx.x];
-    if (i >= LDS_STACK) v = s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride];
+    // Two real branches, one load each.  Left alone, the compiler turns "LDS load or HBM load" into one FLAT load of a
+    // selected address (slower than ds_read, and it ties LDS traffic to vmcnt); the empty asm is a side effect that
+    // cannot be speculated, which keeps the branches and with them the address spaces apart.
+    uint2 v;
+    if (i < LDS_STACK) {
+        v = s_stack[i * TRACE_BLOCK + (int)threadIdx.x];
+        asm volatile("" : "+v"(v.x), "+v"(v.y));
+    } else {
+        v = s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride];
+    }
     return v;
 }
 
