@@ -856,6 +856,12 @@ __global__ void k_mean(const float* sum, const uint32_t* counts, uint32_t n_pixe
     else { const float cf = (float)c; out[f] = sum[f] / cf; out[f + 1] = sum[f + 1] / cf; out[f + 2] = sum[f + 2] / cf; }
 }
 
+// ---- upload time: pack one mesh's shading triangles (pt_types.h ShadeTri) -------------------------
+__global__ void k_build_shade_tris(SceneDev S, MeshRec m, ShadeTri* out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m.n_triangles) out[t] = build_shade_tri(S, m, t);
+}
+
 // ---- tone mapping + sRGB8 on the device (exporter/tonemapping.rs:12-115) ---------------------
 // mode: 0 None, 1 Aces, 2 Reinhard, 3 Agx.  Cuts the readback from 12 B to 3 B per pixel for display / export.
 PT_DEV V3 tm_aces(V3 c) {
@@ -1373,6 +1379,10 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
             tris.push_back(tr);
         }
     }
+    std::vector<uint32_t> shade_base(sc->n_meshes, 0u);
+    uint64_t n_shade_tris = 0;
+    for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) { shade_base[mi] = (uint32_t)n_shade_tris; n_shade_tris += sc->meshes[mi].n_triangles; }
+    if (n_shade_tris > 0xFFFFFFFFull || sc->n_materials > SHADE_MATERIAL_MASK) return fail(ctx, PTX_ERR_UNSUPPORTED, "more than 2^32 triangles or 2^30 materials");
     std::vector<InstRec> inst(sc->n_instances);
     std::vector<InstShade> inst_shade(sc->n_instances);
     for (uint32_t i = 0; i < sc->n_instances; ++i) {
@@ -1391,7 +1401,9 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
         const float* nm = in.normal_matrix;
         InstShade& s = inst_shade[i];
         s.n[0] = nm[0]; s.n[1] = nm[1]; s.n[2] = nm[2]; s.n[3] = nm[4]; s.n[4] = nm[5]; s.n[5] = nm[6]; s.n[6] = nm[8]; s.n[7] = nm[9]; s.n[8] = nm[10];
-        s.mesh_id = in.blas_index; s.pad[0] = s.pad[1] = 0;
+        s.mesh_id = in.blas_index;
+        s.shade_base = shade_base[in.blas_index];
+        s.mat_flags = m.material_id | (m.n_normals ? SHADE_HAS_NORMALS : 0u) | (m.n_uvs ? SHADE_HAS_UVS : 0u);
     }
     std::vector<PtxMaterial> materials(sc->materials, sc->materials + sc->n_materials);
     bool has_sss = false;
@@ -1440,6 +1452,18 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
     S.n_tlas_nodes = sc->n_instances ? n_tlas_records : 0;
     S.tlas_root_word = tlas_root_word;
     S.has_sss = has_sss ? 1u : 0u;
+    // shading triangles: built on the device from the pools just uploaded, one launch per mesh
+    {
+        ShadeTri* d_shade = nullptr;
+        HIPCHK(dev_alloc(pool, &d_shade, (size_t)n_shade_tris));
+        S.shade_tris = d_shade;
+        for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
+            const MeshRec& m = meshes[mi];
+            hipLaunchKernelGGL(k_build_shade_tris, dim3((m.n_triangles + 255) / 256), dim3(256), 0, ctx->stream, S, m, d_shade + shade_base[mi]);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     ctx->S = S;
     ctx->has_scene = true;
     return PTX_OK;

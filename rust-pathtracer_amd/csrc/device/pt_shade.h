@@ -274,29 +274,49 @@ PT_DEV V3 load3(const float* p, uint32_t base, uint32_t i) {
     const float* q = p + base + 3 * (size_t)i;
     return v3(q[0], q[1], q[2]);
 }
-PT_DEV HitData compute_hit_data(const SceneDev& S, uint32_t inst, uint32_t tri_idx, float t, float u, float v) {
-    const InstShade& is = S.inst_shade[inst];
-    const MeshRec& m = S.meshes[is.mesh_id];
+// one ShadeTri from the mesh's vertex pools (upload-time kernel; see pt_types.h)
+PT_DEV ShadeTri build_shade_tri(const SceneDev& S, const MeshRec& m, uint32_t tri_idx) {
     const uint32_t* tri = S.indices + m.idx_base + 3 * (size_t)tri_idx;
     const uint32_t i0 = tri[0], i1 = tri[1], i2 = tri[2];
-    const float w = 1.0f - u - v;
     const V3 v0 = load3(S.positions, m.pos_base, i0), v1 = load3(S.positions, m.pos_base, i1), v2 = load3(S.positions, m.pos_base, i2);
-    const V3 face_normal = normalize(cross(v1 - v0, v2 - v0));
+    const V3 fn = normalize(cross(v1 - v0, v2 - v0));
+    V3 n0 = splat(0.0f), n1 = n0, n2 = n0;
+    if (m.nrm_base != 0xFFFFFFFFu) { n0 = load3(S.normals, m.nrm_base, i0); n1 = load3(S.normals, m.nrm_base, i1); n2 = load3(S.normals, m.nrm_base, i2); }
+    float u0 = 0.0f, w0 = 0.0f, u1 = 0.0f, w1 = 0.0f, u2 = 0.0f, w2 = 0.0f;
+    if (m.uv_base != 0xFFFFFFFFu) {
+        const float* a = S.uvs + m.uv_base + 2 * (size_t)i0;
+        const float* b = S.uvs + m.uv_base + 2 * (size_t)i1;
+        const float* c = S.uvs + m.uv_base + 2 * (size_t)i2;
+        u0 = a[0]; w0 = a[1]; u1 = b[0]; w1 = b[1]; u2 = c[0]; w2 = c[1];
+    }
+    ShadeTri r;
+    r.a = make_float4(fn.x, fn.y, fn.z, n0.x);
+    r.b = make_float4(n0.y, n0.z, n1.x, n1.y);
+    r.c = make_float4(n1.z, n2.x, n2.y, n2.z);
+    r.d = make_float4(u0, w0, u1, w1);
+    r.e = make_float4(u2, w2, 0.0f, 0.0f);
+    return r;
+}
+
+PT_DEV HitData compute_hit_data(const SceneDev& S, uint32_t inst, uint32_t tri_idx, float t, float u, float v) {
+    const InstShade& is = S.inst_shade[inst];
+    const float4* q = reinterpret_cast<const float4*>(&S.shade_tris[(size_t)is.shade_base + tri_idx]);
+    const float4 qa = q[0], qb = q[1], qc = q[2], qd = q[3], qe = q[4];
+    const uint32_t mat_flags = is.mat_flags;
+    const float w = 1.0f - u - v;
+    const V3 face_normal = v3(qa.x, qa.y, qa.z);
     V3 normal;
-    if (m.nrm_base != 0xFFFFFFFFu) {
-        const V3 n0 = load3(S.normals, m.nrm_base, i0), n1 = load3(S.normals, m.nrm_base, i1), n2 = load3(S.normals, m.nrm_base, i2);
+    if (mat_flags & SHADE_HAS_NORMALS) {
+        const V3 n0 = v3(qa.w, qb.x, qb.y), n1 = v3(qb.z, qb.w, qc.x), n2 = v3(qc.y, qc.z, qc.w);
         normal = normalize(n0 * w + n1 * u + n2 * v);
     } else {
         normal = face_normal;
     }
     const V3 geo_normal = (dot(face_normal, normal) >= 0.0f) ? face_normal : -face_normal;
     HitData h;
-    if (m.uv_base != 0xFFFFFFFFu) {
-        const float* a = S.uvs + m.uv_base + 2 * (size_t)i0;
-        const float* b = S.uvs + m.uv_base + 2 * (size_t)i1;
-        const float* c = S.uvs + m.uv_base + 2 * (size_t)i2;
-        h.uvx = (a[0] * w + b[0] * u) + c[0] * v;
-        h.uvy = (a[1] * w + b[1] * u) + c[1] * v;
+    if (mat_flags & SHADE_HAS_UVS) {
+        h.uvx = (qd.x * w + qd.z * u) + qe.x * v;
+        h.uvy = (qd.y * w + qd.w * u) + qe.y * v;
     } else {
         h.uvx = u; h.uvy = v;
     }
@@ -305,7 +325,7 @@ PT_DEV HitData compute_hit_data(const SceneDev& S, uint32_t inst, uint32_t tri_i
     h.tangent = normalize(cross(up, normal));
     h.bitangent = cross(normal, h.tangent);
     h.t = t;
-    h.material_id = m.material_id;
+    h.material_id = mat_flags & SHADE_MATERIAL_MASK;
     // normal_matrix.transform_vector3(n).normalize()
     const float* nm = is.n;
     h.normal = normalize(v3((nm[0] * normal.x + nm[3] * normal.y) + nm[6] * normal.z,

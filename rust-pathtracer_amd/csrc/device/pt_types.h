@@ -52,7 +52,19 @@ struct InstRec { float4 m[8]; };
 static_assert(sizeof(InstRec) == 128, "instance record");
 
 // normal_matrix 3x3 part (x.xyz, y.xyz, z.xyz) + mesh id: read once per path vertex
-struct InstShade { float n[9]; uint32_t mesh_id; uint32_t pad[2]; };
+// shade_base = first ShadeTri of the instance's mesh; mat_flags = material id | SHADE_HAS_NORMALS | SHADE_HAS_UVS, so a
+// path vertex reaches its shading data in two dependent reads (InstShade -> ShadeTri) instead of four
+struct InstShade { float n[9]; uint32_t mesh_id; uint32_t shade_base; uint32_t mat_flags; };
+constexpr uint32_t SHADE_HAS_NORMALS = 0x80000000u, SHADE_HAS_UVS = 0x40000000u, SHADE_MATERIAL_MASK = 0x3FFFFFFFu;
+
+// ---- shading triangle: 80 B, by the mesh's own triangle index ----------------------------
+//   a = (face_normal.xyz, n0.x)  b = (n0.yz, n1.xy)  c = (n1.z, n2.xyz)  d = (uv0, uv1)  e = (uv2, -, -)
+// Everything compute_hit_data (shape/triangle_mesh.rs:102-190) gathers per hit — index triple, three positions, three
+// normals, three uvs: ten scattered 64-B sectors — packed at upload into one record (two sectors).  face_normal =
+// normalize(cross(v1 - v0, v2 - v0)) is evaluated once per triangle by a device kernel with the very code a path
+// vertex used to run, so the bits are the same.
+struct ShadeTri { float4 a, b, c, d, e; };
+static_assert(sizeof(ShadeTri) == 80, "shading triangle record");
 
 struct MeshRec {
     uint32_t pos_base;      // float index into positions
@@ -78,6 +90,7 @@ struct SceneDev {
     const InstRec* inst_tlas;      // the same records in TLAS primitive_indices order (one load fewer per entry)
     const InstShade* inst_shade;
     const MeshRec* meshes;
+    const ShadeTri* shade_tris;
     const float* positions;
     const float* normals;
     const float* uvs;
