@@ -454,7 +454,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                         {
                             const float u1 = rng.next();
                             const float u2 = rng.next();
-                            const SkySample ss = sky_sample_direction(S, u1, u2, sc);
+                            const SkySample ss = sky_sample_direction<!CNT>(S, u1, u2, sc);
                             const V3 l = ss.direction;
                             const float n_dot_l = dot(nrm, l);
                             if (!(n_dot_l <= 0.0f || ss.pdf <= 0.0f)) {
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                         {
                             const float u1 = rng.next();
                             const float u2 = rng.next();
-                            const SkySample ss = sky_sample_direction(S, u1, u2, sc);
+                            const SkySample ss = sky_sample_direction<!CNT>(S, u1, u2, sc);
                             const float n_dot_l = dot(exit_n, ss.direction);
                             if (n_dot_l > 0.0f && ss.pdf > 0.0f) {
                                 const V3 sky_contribution = clamp_radiance(ss.radiance * safe_inv_pdf(ss.pdf));
@@ -1444,6 +1444,52 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
     HIPCHK(dev_upload(pool, &S.positions, positions)); HIPCHK(dev_upload(pool, &S.normals, normals)); HIPCHK(dev_upload(pool, &S.uvs, uvs));
     HIPCHK(dev_upload(pool, &S.indices, indices)); HIPCHK(dev_upload(pool, &S.materials, materials)); HIPCHK(dev_upload(pool, &S.textures, textures));
     HIPCHK(dev_upload(pool, &S.texels, texels)); HIPCHK(dev_upload(pool, &S.sky_marginal, marginal)); HIPCHK(dev_upload(pool, &S.sky_conditional, conditional));
+    {
+        // 16-ary search tables (pt_types.h): only for non-decreasing CDFs, where counting equals the reference's bisection
+        bool monotone = true;
+        for (uint32_t i = 0; i + 1 < S.sky_h + 1 && monotone; ++i) monotone = marginal[i] <= marginal[i + 1];
+        for (size_t r = 0; r < S.sky_h && monotone; ++r)
+            for (uint32_t i = 0; i < S.sky_w && monotone; ++i) monotone = conditional[r * (S.sky_w + 1) + i] <= conditional[r * (S.sky_w + 1) + i + 1];
+        std::vector<float> search;
+        const float inf = __builtin_inff();
+        auto level_sizes = [](uint32_t n_real, uint32_t* sizes) {   // padded sizes per level; returns the level count (0 = too large)
+            uint32_t levels = 0, n = n_real;
+            for (;;) {
+                if (levels == 4) return 0u;
+                const uint32_t padded = (n + 1u + 15u) / 16u * 16u;
+                sizes[levels++] = padded;
+                if (padded == 16u) return levels;
+                n = padded / 16u;
+            }
+        };
+        uint32_t sm[4] = {0, 0, 0, 0}, scs[4] = {0, 0, 0, 0};
+        const uint32_t lm = level_sizes(S.sky_h, sm), lc = level_sizes(S.sky_w, scs);
+        if (monotone && lm && lc && S.sky_total_weight > 0.0f) {
+            auto build = [&](const float* cdf, uint32_t n_real, const uint32_t* sizes, uint32_t levels, const size_t* offs, size_t row, const uint32_t* strides) {
+                // level 0
+                float* l0 = &search[offs[0] + row * strides[0]];
+                for (uint32_t i = 0; i < sizes[0]; ++i) l0[i] = i < n_real ? cdf[i] : inf;
+                for (uint32_t l = 1; l < levels; ++l) {
+                    const float* below = &search[offs[l - 1] + row * strides[l - 1]];
+                    float* cur = &search[offs[l] + row * strides[l]];
+                    const uint32_t groups = sizes[l - 1] / 16u;
+                    for (uint32_t i = 0; i < sizes[l]; ++i) cur[i] = i < groups ? below[16u * i + 15u] : inf;
+                }
+            };
+            size_t total = 0, off_m[4] = {0, 0, 0, 0}, off_c[4] = {0, 0, 0, 0};
+            for (uint32_t l = 0; l < lm; ++l) { off_m[l] = total; total += sm[l]; }
+            for (uint32_t l = 0; l < lc; ++l) { off_c[l] = total; total += (size_t)scs[l] * S.sky_h; }
+            if (total < 0xFFFFFFFFull) {
+                search.assign(total, inf);
+                const uint32_t zero[4] = {0, 0, 0, 0};
+                build(marginal.data(), S.sky_h, sm, lm, off_m, 0, zero);
+                for (size_t r = 0; r < S.sky_h; ++r) build(&conditional[r * (S.sky_w + 1)], S.sky_w, scs, lc, off_c, r, scs);
+                S.cdf_levels_m = lm; S.cdf_levels_c = lc;
+                for (uint32_t l = 0; l < 4; ++l) { S.cdf_off_m[l] = (uint32_t)off_m[l]; S.cdf_off_c[l] = (uint32_t)off_c[l]; S.cdf_stride_c[l] = scs[l]; }
+            }
+        }
+        HIPCHK(dev_upload(pool, &S.sky_search, search));
+    }
     HIPCHK(dev_upload(pool, &S.bn_pixel, bn_pixel)); HIPCHK(dev_upload(pool, &S.bn_lens, bn_lens));
     S.bn_size = sc->blue_noise_pixel.size;
     S.sun_enabled = sc->sun.enabled;

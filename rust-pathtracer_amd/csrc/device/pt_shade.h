@@ -107,7 +107,24 @@ PT_DEV uint32_t cdf_search(const float* cdf, uint32_t len, float u, uint32_t& pr
     }
     return lo == 0 ? 0 : lo - 1;
 }
+// The same index without the dependent chain of ~log2(len) probes: for a non-decreasing CDF the loop above returns
+// lo = #{i <= len-2 : cdf[i] <= u}, and that count is found 16 entries (one 64-B sector) per level.
+PT_DEV uint32_t cdf_count16(const float* tab, const uint32_t* off, const uint32_t* stride, uint32_t row, uint32_t levels, float u) {
+    uint32_t g = 0;
+    for (int l = (int)levels - 1; l >= 0; --l) {
+        const float4* p = reinterpret_cast<const float4*>(tab + off[l] + (size_t)row * stride[l] + 16u * g);
+        const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+        const uint32_t n = (uint32_t)(a.x <= u) + (uint32_t)(a.y <= u) + (uint32_t)(a.z <= u) + (uint32_t)(a.w <= u) +
+                           (uint32_t)(b.x <= u) + (uint32_t)(b.y <= u) + (uint32_t)(b.z <= u) + (uint32_t)(b.w <= u) +
+                           (uint32_t)(c.x <= u) + (uint32_t)(c.y <= u) + (uint32_t)(c.z <= u) + (uint32_t)(c.w <= u) +
+                           (uint32_t)(d.x <= u) + (uint32_t)(d.y <= u) + (uint32_t)(d.z <= u) + (uint32_t)(d.w <= u);
+        g = 16u * g + n;
+    }
+    return g;
+}
 struct SkySample { V3 direction, radiance; float pdf; };
+// FAST: use the 16-ary tables when the scene has them (the counting kernels keep the reference's probe sequence)
+template <bool FAST>
 PT_DEV SkySample sky_sample_direction(const SceneDev& S, float u1, float u2, ShadeCnt& sc) {
     SkySample r;
     if (S.sky_total_weight <= 0.0f) {
@@ -125,12 +142,17 @@ PT_DEV SkySample sky_sample_direction(const SceneDev& S, float u1, float u2, Sha
 #ifdef PT_EXP_NO_CDF
     r.direction = v3(0.0f, 1.0f, 0.0f); r.radiance = v3(1.0f, 1.0f, 1.0f); r.pdf = 1.0f + u1 + u2; return r;
 #endif
-    const uint32_t y = cdf_search(S.sky_marginal, H + 1, u1, sc.cdf_probes);
+    const uint32_t zero_stride[4] = {0u, 0u, 0u, 0u};
+    uint32_t y;
+    if (FAST && S.cdf_levels_m) { const uint32_t lo = cdf_count16(S.sky_search, S.cdf_off_m, zero_stride, 0u, S.cdf_levels_m, u1); y = lo == 0u ? 0u : lo - 1u; }
+    else y = cdf_search(S.sky_marginal, H + 1, u1, sc.cdf_probes);
     const float v_lo = S.sky_marginal[y], v_hi = S.sky_marginal[y + 1];
     const float dv = (u1 - v_lo) / (v_hi - v_lo + 1e-10f);
     const float v = ((float)y + dv) / (float)H;
     const float* row_cdf = S.sky_conditional + (size_t)y * (W + 1);
-    const uint32_t x = cdf_search(row_cdf, W + 1, u2, sc.cdf_probes);
+    uint32_t x;
+    if (FAST && S.cdf_levels_c) { const uint32_t lo = cdf_count16(S.sky_search, S.cdf_off_c, S.cdf_stride_c, y, S.cdf_levels_c, u2); x = lo == 0u ? 0u : lo - 1u; }
+    else x = cdf_search(row_cdf, W + 1, u2, sc.cdf_probes);
     const float u_lo = row_cdf[x], u_hi = row_cdf[x + 1];
     const float du = (u2 - u_lo) / (u_hi - u_lo + 1e-10f);
     const float u = ((float)x + du) / (float)W;

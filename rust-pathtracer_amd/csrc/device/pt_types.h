@@ -102,6 +102,13 @@ struct SceneDev {
     TexRec sky_tex;
     const float* sky_marginal;
     const float* sky_conditional;
+    // 16-ary search tables over the two CDFs (built at upload when both are non-decreasing; see cdf_count16):
+    // level 0 = the CDF without its last entry, padded with +inf to a multiple of 16 (at least one pad); level l+1 =
+    // every 16th entry (the group maxima) of level l, padded the same way; the top level is one group.
+    const float* sky_search;           // all levels of the marginal, then all levels of every conditional row
+    uint32_t cdf_levels_m, cdf_levels_c;   // 0 = tables absent: binary search
+    uint32_t cdf_off_m[4];                 // float offset of marginal level l
+    uint32_t cdf_off_c[4], cdf_stride_c[4];   // conditional level l: offset of row 0, floats per row
     uint32_t sky_w, sky_h;
     float sky_total_weight, sky_rotation;
     // sun
