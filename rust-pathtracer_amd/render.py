@@ -290,6 +290,33 @@ def combine_framebuffers(dist, buffers):
     return buffers
 
 
+def render_frame_distributed(all_reduce_max, loop, fb, scene, camera, renderer, spp, adaptive=None, max_spp=0):
+    """One rank's share of `ptx_render_frame` when the frame is split over several GPUs (`loop.set_partition`).
+
+    Uniform passes need no communication.  The adaptive phase (app.rs:195-236) does not either, except for its stop
+    rule: a pixel's sample sequence depends only on its own sums (it is sampled in a pass iff it is noisy then), and
+    every rank selects the noisy pixels among its own interleaved 8x8 tiles — that selection IS the variance-driven
+    redistribution, tile interleave spreads noisy regions over the ranks — so ranks run their passes independently.
+    Only "stop when any pixel has max_spp samples" is global: one 4-byte all-reduce(MAX) per pass
+    (`all_reduce_max(int) -> int`; torch.distributed over RCCL on GPUs, gloo or a stub in tests).  A rank whose pixels
+    have converged keeps answering the collective with an empty pass.  Afterwards `combine_framebuffers` merges the
+    ranks' buffers; the result is bit-identical to the single-GPU frame.  Returns this rank's adaptive sample count."""
+    fb._require(loop)
+    fb.reset()
+    fb.render_passes(scene, camera, renderer, 0, spp)
+    rendered = 0
+    if adaptive is not None and max_spp:
+        while True:
+            mx = all_reduce_max(fb.stats()[1])
+            if mx >= max_spp:
+                break
+            n = loop.render_adaptive_pass(scene, camera, renderer, fb, adaptive)
+            rendered += n
+            if all_reduce_max(n) == 0:
+                break
+    return rendered
+
+
 class DeviceFramebuffer:
     """`Framebuffer` / `AdaptiveFramebuffer` (framebuffer.rs:10-60, 76-229) kept in HBM.
 

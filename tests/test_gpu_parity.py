@@ -289,6 +289,50 @@ def test_device_tonemap_srgb8(pkg, loop, oracle_det, scenes):
     assert np.array_equal(bits(loop.debug_math("log2", x[:5002])), bits(oracle_det.math("log2", x[:5002])))
 
 
+def test_adaptive_frame_split_over_ranks_is_the_single_gpu_frame(pkg, loop, scenes):
+    """BASELINE config 5 on several GPUs: every rank runs uniform + adaptive passes on its interleaved tiles, sharing
+    only the stop rule (one all-reduce(MAX) per pass); the combined buffers equal the 1-GPU frame bit for bit.  Three
+    virtual ranks = three contexts on this GPU, one thread each, a barrier standing in for the collective."""
+    import threading
+    sc = scenes("cornell", 1, 1.0)
+    w, h, spp, cap, world = 72, 40, 5, 11, 3
+    cam = sc.default_camera(w / h)
+    cfg = pkg.AdaptiveSamplingConfig(min_samples=4, variance_threshold=0.03)
+    mean, counts, stats = loop.render_frame(sc, cam, pkg.PathTracer(8), w, h, spp, adaptive=cfg, max_spp=cap)
+    assert stats["adaptive_passes"] >= 3 and counts.max() == cap and counts.min() < cap
+    barrier, vals, parts, errors = threading.Barrier(world), [0] * world, [None] * world, []
+
+    def rank_main(r):
+        try:
+            def all_reduce_max(v):
+                vals[r] = int(v)
+                barrier.wait()
+                m = max(vals)
+                barrier.wait()
+                return m
+            lp = pkg.HipRenderLoop(0)
+            lp.set_partition(r, world)
+            fb = pkg.DeviceFramebuffer(lp, w, h, adaptive=True)
+            pkg.render.render_frame_distributed(all_reduce_max, lp, fb, sc, cam, pkg.PathTracer(8), spp, adaptive=cfg, max_spp=cap)
+            parts[r] = fb.read()
+        except Exception as e:   # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    total = [sum(p[k] for p in parts) for k in range(3)]          # combine_framebuffers: disjoint tiles + zeros
+    single = pkg.DeviceFramebuffer(loop, w, h, adaptive=True)     # same frame again, raw accumulators this time
+    pkg.render.render_frame_distributed(lambda v: int(v), loop, single, sc, cam, pkg.PathTracer(8), spp, adaptive=cfg, max_spp=cap)
+    want = single.read()
+    assert np.array_equal(want[2], counts) and np.array_equal(total[2], want[2])
+    assert np.array_equal(bits(total[0]), bits(want[0])) and np.array_equal(bits(total[1]), bits(want[1]))
+
+
 def _widen_bvh_in_place(bvh, rng):
     """Pull internal children's slots up into their parent while the parent stays <= 8 wide, and scatter the valid
     slots over the 8 positions: nodes a true 8-wide collapse would produce (the reference's own builder stops at 3)."""
