@@ -298,6 +298,20 @@ int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t co
 int32_t ptx_fb_adaptive_pass(PtxContext* ctx, const PtxAdaptiveConfig* cfg,
                              uint32_t max_bounces, uint64_t* out_rendered);
 
+/* The adaptive loop of the app (app.rs:195-236: `render_adaptive_pass` once per
+ * frame until it renders nothing): up to `max_passes` passes, stopping after
+ * the first that finds no noisy pixel.  Same sum / sum_sq / counts as calling
+ * ptx_fb_adaptive_pass that many times, bit for bit: a pixel's sums change only
+ * when it is sampled and sample k of a pixel has `sample_index = its count`
+ * (parallel.rs:109-114), so several passes are traced together (32 by default,
+ * PTX_ADAPTIVE_BATCH) and replayed per pixel in pass order, dropping the
+ * samples of passes the pixel would have sat out.  With counters on, or when
+ * max_samples_per_pass truncates the list, it runs one pass at a time.
+ * *out_passes = passes that rendered something, *out_rendered = samples added. */
+int32_t ptx_fb_adaptive_passes(PtxContext* ctx, const PtxAdaptiveConfig* cfg,
+                               uint32_t max_bounces, uint32_t max_passes,
+                               uint32_t* out_passes, uint64_t* out_rendered);
+
 /* `min_sample_count` / `max_sample_count` / `total_samples`
  * (framebuffer.rs:132-142) over the pixels this context owns. */
 int32_t ptx_fb_stats(PtxContext* ctx, uint32_t* out_min, uint32_t* out_max,

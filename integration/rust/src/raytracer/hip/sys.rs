@@ -178,6 +178,7 @@ extern "C" {
     pub fn ptx_fb_reset(ctx: *mut PtxContext, w: u32, h: u32, adaptive: i32) -> i32;
     pub fn ptx_fb_render_passes(ctx: *mut PtxContext, first_sample: u32, count: u32, max_bounces: u32) -> i32;
     pub fn ptx_fb_adaptive_pass(ctx: *mut PtxContext, cfg: *const PtxAdaptiveConfig, max_bounces: u32, out_rendered: *mut u64) -> i32;
+    pub fn ptx_fb_adaptive_passes(ctx: *mut PtxContext, cfg: *const PtxAdaptiveConfig, max_bounces: u32, max_passes: u32, out_passes: *mut u32, out_rendered: *mut u64) -> i32;
     pub fn ptx_fb_stats(ctx: *mut PtxContext, out_min: *mut u32, out_max: *mut u32, out_total: *mut u64) -> i32;
     pub fn ptx_fb_read(ctx: *mut PtxContext, out_sum: *mut f32, out_sum_sq: *mut f32, out_counts: *mut u32) -> i32;
     pub fn ptx_fb_read_mean(ctx: *mut PtxContext, out_mean: *mut f32) -> i32;

@@ -178,8 +178,8 @@ __global__ void k_raygen(SceneDev S, CameraDev cam, PathArrays P, const uint32_t
     if (i >= n) return;
     // stride != 0: slots [k*stride, (k+1)*stride) are sample uniform_sample + k of the same `stride` pixels
     const uint32_t pixel = wl_pixel[stride ? i % stride : i];
-    // sample index: explicit list (render_pixels), the pixel's own count (adaptive), or the pass's
-    const uint32_t sample_index = wl_sample ? wl_sample[i] : (fb_counts ? fb_counts[pixel] : uniform_sample + (stride ? i / stride : 0u));
+    // sample index: explicit list (render_pixels), the pixel's own count (adaptive), or the pass's; + k for slot block k
+    const uint32_t sample_index = wl_sample ? wl_sample[i] : (fb_counts ? fb_counts[pixel] : uniform_sample) + (stride ? i / stride : 0u);
     const uint32_t x = pixel % width, y = pixel / width;
     float px, py, lx, ly;
     bluenoise_sample(S.bn_pixel, S.bn_size, x, y, sample_index, &px, &py);
@@ -793,6 +793,16 @@ __global__ void k_unshaded(SceneDev S, PathArrays P, uint32_t n, float* out_rgb)
 }
 
 // ---- adaptive: get_noisy_pixels (framebuffer.rs:181-214) ------------------------------
+PT_DEV bool pixel_noisy(uint32_t count, V3 sum, V3 sum_sq, uint32_t min_samples, float threshold, float* err) {
+    if (count < min_samples) { *err = PT_INF; return true; }
+    const float nf = (float)count;
+    const V3 mean = sum / nf;
+    const V3 mean_sq = sum_sq / nf;
+    const V3 variance = mean_sq - mean * mean;
+    const float var_scalar = (f_max(variance.x, 0.0f) + f_max(variance.y, 0.0f) + f_max(variance.z, 0.0f)) / 3.0f;
+    *err = sqrtf(var_scalar / nf);
+    return *err > threshold;
+}
 __global__ void k_noise_keys(const uint32_t* owned, uint32_t n, const float* sum, const float* sum_sq, const uint32_t* counts,
                              uint32_t min_samples, float threshold, uint32_t* keys, uint32_t* n_noisy) {
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -801,24 +811,51 @@ __global__ void k_noise_keys(const uint32_t* owned, uint32_t n, const float* sum
         bool noisy = false;
         if (i < n) {
             const uint32_t pixel = owned[i];
-            const uint32_t count = counts[pixel];
+            const size_t f = (size_t)pixel * 3;
             float err;
-            if (count < min_samples) { err = PT_INF; noisy = true; }
-            else {
-                const float nf = (float)count;
-                const size_t f = (size_t)pixel * 3;
-                const V3 mean = v3(sum[f], sum[f + 1], sum[f + 2]) / nf;
-                const V3 mean_sq = v3(sum_sq[f], sum_sq[f + 1], sum_sq[f + 2]) / nf;
-                const V3 variance = mean_sq - mean * mean;
-                const float var_scalar = (f_max(variance.x, 0.0f) + f_max(variance.y, 0.0f) + f_max(variance.z, 0.0f)) / 3.0f;
-                err = sqrtf(var_scalar / nf);
-                noisy = err > threshold;
-            }
+            noisy = pixel_noisy(counts[pixel], v3(sum[f], sum[f + 1], sum[f + 2]), v3(sum_sq[f], sum_sq[f + 1], sum_sq[f + 2]),
+                                min_samples, threshold, &err);
             // key 0 = not selected; selected keys keep the f32 order of err (err >= 0), +1 so that err == 0 stays selected
             keys[i] = noisy ? (__float_as_uint(err) + 1u) : 0u;
         }
         const unsigned long long m = __ballot(noisy);
         if ((threadIdx.x & 63u) == 0u && m) atomicAdd(n_noisy, (uint32_t)__popcll(m));
+    }
+}
+// `batch` adaptive passes traced together for the `n` pixels of `work`: slot k*n + i holds the sample the pixel would
+// get in pass k IF it is still noisy then (sample_index = its count, parallel.rs:109-114).  A pixel's sums change only
+// when it is sampled, so replaying the passes per pixel — add sample k, stop at the first pass that finds the pixel
+// converged, drop the rest — leaves sum / sum_sq / count exactly as `batch` separate passes would.
+// out[0] = passes that rendered something (max samples applied to one pixel), out[1..2] = samples applied (u64).
+__global__ void k_accumulate_adaptive(PathArrays P, const uint32_t* work, uint32_t n, uint32_t batch, uint32_t min_samples,
+                                      float threshold, Target tg, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t applied = 0;
+    if (i < n) {
+        const uint32_t pixel = work[i];
+        const size_t f = (size_t)pixel * 3;
+        V3 s1 = v3(tg.sum[f], tg.sum[f + 1], tg.sum[f + 2]);
+        V3 s2 = v3(tg.sum_sq[f], tg.sum_sq[f + 1], tg.sum_sq[f + 2]);
+        uint32_t count = tg.counts[pixel];
+        for (uint32_t k = 0; k < batch; ++k) {
+            float err;
+            if (!pixel_noisy(count, s1, s2, min_samples, threshold, &err)) break;
+            const float4 c = P.rad[(size_t)k * n + i];
+            s1 = v3(s1.x + c.x, s1.y + c.y, s1.z + c.z);
+            s2 = v3(s2.x + c.x * c.x, s2.y + c.y * c.y, s2.z + c.z * c.z);
+            count += 1u;
+            applied += 1u;
+        }
+        tg.sum[f] = s1.x; tg.sum[f + 1] = s1.y; tg.sum[f + 2] = s1.z;
+        tg.sum_sq[f] = s2.x; tg.sum_sq[f + 1] = s2.y; tg.sum_sq[f + 2] = s2.z;
+        tg.counts[pixel] = count;
+    }
+    uint32_t mx = applied, total = applied;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor(mx, off)); total += __shfl_xor(total, off); }
+    if ((threadIdx.x & 63u) == 0u && total) {
+        atomicMax(out, mx);
+        atomicAdd(reinterpret_cast<unsigned long long*>(out + 2), (unsigned long long)total);
     }
 }
 __global__ void k_compact_noisy(const uint32_t* owned, const uint32_t* keys, uint32_t n, uint32_t* out, uint32_t* out_count) {
@@ -980,6 +1017,7 @@ struct PtxContext {
     uint32_t fb_w = 0, fb_h = 0; bool fb_adaptive = false;
     float *fb_sum = nullptr, *fb_sum_sq = nullptr; uint32_t* fb_counts = nullptr;
 
+    uint32_t adaptive_batch = 32;   // adaptive passes traced together by ptx_fb_adaptive_passes (PTX_ADAPTIVE_BATCH)
     bool counting = false, profiling = false;
     struct Ev { hipEvent_t a, b; int cls; };
     std::vector<Ev> events;
@@ -1290,6 +1328,10 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
     if (const char* e = std::getenv("PTX_PATHS_IN_FLIGHT")) {
         const unsigned long long v = std::strtoull(e, nullptr, 10);
         if (v) c->max_paths_in_flight = v;
+    }
+    if (const char* e = std::getenv("PTX_ADAPTIVE_BATCH")) {
+        const unsigned long v = std::strtoul(e, nullptr, 10);
+        if (v) c->adaptive_batch = (uint32_t)std::min<unsigned long>(v, 256);
     }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * MAX_ITERS));
@@ -1728,6 +1770,67 @@ int32_t ptx_fb_adaptive_pass(PtxContext* ctx, const PtxAdaptiveConfig* cfg, uint
     return check_device_error(ctx);
 }
 
+int32_t ptx_fb_adaptive_passes(PtxContext* ctx, const PtxAdaptiveConfig* cfg, uint32_t max_bounces, uint32_t max_passes,
+                               uint32_t* out_passes, uint64_t* out_rendered) {
+    REQUIRE_FB();
+    if (!cfg || !out_passes || !out_rendered) return fail(ctx, PTX_ERR_INVALID, "null argument");
+    if (!ctx->fb_adaptive) return fail(ctx, PTX_ERR_INVALID, "framebuffer was not created adaptive");
+    *out_passes = 0; *out_rendered = 0;
+    int32_t st = ensure_worklist(ctx, ctx->fb_w, ctx->fb_h);
+    if (st != PTX_OK) return st;
+    const uint32_t n = ctx->wl_n;
+    if (n == 0) return PTX_OK;
+    st = ensure_lists(ctx, n);
+    if (st != PTX_OK) return st;
+    uint32_t* keys = ctx->list_b; uint32_t* work = ctx->list_c;
+    uint32_t* d_count = reinterpret_cast<uint32_t*>(&ctx->ctrs[MAX_ITERS - 1]);   // spare counter block
+    const int grid = (int)std::min<uint32_t>(2048, (n + 255) / 256);
+    uint32_t passes = 0; uint64_t rendered = 0;
+    while (passes < max_passes) {
+        HIPCHK(hipMemsetAsync(d_count, 0, sizeof(IterCtr), ctx->stream));
+        hipLaunchKernelGGL(k_noise_keys, dim3(grid), dim3(256), 0, ctx->stream, ctx->wl_pixel, n, ctx->fb_sum, ctx->fb_sum_sq, ctx->fb_counts,
+                           cfg->min_samples, cfg->variance_threshold, keys, d_count);
+        HIPCHK(hipMemcpyAsync(ctx->h_pinned + 2, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const uint32_t n_noisy = ctx->h_pinned[2];
+        if (n_noisy == 0) break;
+        // passes in flight: every noisy pixel gets `b` speculative samples; k_accumulate_adaptive keeps the ones the
+        // pass-at-a-time loop would have taken.  Device counters would include the dropped samples, and a truncated
+        // work list couples the pixels, so both cases go one pass at a time.
+        const uint32_t b = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(ctx->adaptive_batch, max_passes - passes),
+                                                        std::max<uint64_t>(1, ctx->max_paths_in_flight / n_noisy));
+        if (ctx->counting || b <= 1 || (uint64_t)n_noisy > cfg->max_samples_per_pass) {
+            uint64_t r = 0;
+            st = ptx_fb_adaptive_pass(ctx, cfg, max_bounces, &r);
+            if (st != PTX_OK) return st;
+            if (r == 0) break;
+            passes += 1; rendered += r;
+            continue;
+        }
+        hipLaunchKernelGGL(k_compact_noisy, dim3(grid), dim3(256), 0, ctx->stream, ctx->wl_pixel, keys, n, work, d_count + 1);
+        Target tg{};
+        tg.sum = ctx->fb_sum; tg.sum_sq = ctx->fb_sum_sq; tg.counts = ctx->fb_counts;
+        Target deferred = tg;
+        deferred.defer = 1u;
+        st = run_paths(ctx, work, nullptr, ctx->fb_counts, 0, n_noisy * b, ctx->fb_w, ctx->fb_h, max_bounces, deferred, false, n_noisy);
+        if (st != PTX_OK) return st;
+        HIPCHK(hipMemsetAsync(d_count, 0, sizeof(IterCtr), ctx->stream));
+        {
+            ScopedEvent ev(ctx, CLS_ACCUM);
+            hipLaunchKernelGGL(k_accumulate_adaptive, dim3((n_noisy + 255) / 256), dim3(256), 0, ctx->stream, ctx->P, work, n_noisy, b,
+                               cfg->min_samples, cfg->variance_threshold, tg, d_count);
+        }
+        HIPCHK(hipMemcpyAsync(ctx->h_pinned + 8, d_count, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const uint32_t applied_max = ctx->h_pinned[8];
+        const uint64_t applied = (uint64_t)ctx->h_pinned[10] | ((uint64_t)ctx->h_pinned[11] << 32);
+        passes += applied_max; rendered += applied;
+        if (applied_max < b) break;    // the next pass would find no noisy pixel
+    }
+    *out_passes = passes; *out_rendered = rendered;
+    return check_device_error(ctx);
+}
+
 int32_t ptx_fb_stats(PtxContext* ctx, uint32_t* out_min, uint32_t* out_max, uint64_t* out_total) {
     REQUIRE_CTX();
     if (!ctx->fb_sum) return fail(ctx, PTX_ERR_INVALID, "no framebuffer: call ptx_fb_reset");
@@ -1803,19 +1906,14 @@ int32_t ptx_render_frame(PtxContext* ctx, uint32_t width, uint32_t height, uint3
     if (st != PTX_OK) return st;
     PtxFrameStats fs{};
     fs.uniform_passes = spp;
-    if (adaptive && max_spp) {
-        for (;;) {
-            uint32_t mn = 0, mx = 0; uint64_t total = 0;
-            st = ptx_fb_stats(ctx, &mn, &mx, &total);
-            if (st != PTX_OK) return st;
-            if (mx >= max_spp) break;
-            uint64_t rendered = 0;
-            st = ptx_fb_adaptive_pass(ctx, adaptive, max_bounces, &rendered);
-            if (st != PTX_OK) return st;
-            if (rendered == 0) break;             // app.rs: the frame has converged
-            fs.adaptive_passes++;
-            fs.adaptive_samples += rendered;
-        }
+    if (adaptive && max_spp > spp) {
+        // every pixel starts at `spp` samples and a noisy pixel is sampled in every pass, so "stop once a pixel holds
+        // max_spp samples" (app.rs) is a cap of max_spp - spp passes
+        uint32_t passes = 0; uint64_t rendered = 0;
+        st = ptx_fb_adaptive_passes(ctx, adaptive, max_bounces, max_spp - spp, &passes, &rendered);
+        if (st != PTX_OK) return st;
+        fs.adaptive_passes = passes;
+        fs.adaptive_samples = rendered;
     }
     st = ptx_fb_stats(ctx, &fs.min_samples, &fs.max_samples, &fs.total_samples);
     if (st != PTX_OK) return st;

@@ -22,7 +22,7 @@ EXPORTS = [
     "ptx_fb_reset", "ptx_fb_render_passes", "ptx_fb_adaptive_pass", "ptx_fb_stats", "ptx_fb_read",
     "ptx_fb_read_mean", "ptx_fb_export_dev", "ptx_sync", "ptx_trace_batch", "ptx_generate_primary_rays",
     "ptx_set_counting", "ptx_reset_counters", "ptx_get_counters", "ptx_set_profiling", "ptx_reset_timings",
-    "ptx_get_timings", "ptx_debug_math", "ptx_render_frame", "ptx_fb_tonemap_srgb8",
+    "ptx_get_timings", "ptx_debug_math", "ptx_render_frame", "ptx_fb_tonemap_srgb8", "ptx_fb_adaptive_passes",
 ]
 
 
@@ -57,6 +57,7 @@ def lib():
     L.ptx_fb_reset.argtypes = [vp, u32, u32, i32]
     L.ptx_fb_render_passes.argtypes = [vp, u32, u32, u32]
     L.ptx_fb_adaptive_pass.argtypes = [vp, C.POINTER(abi.PtxAdaptiveConfig), u32, C.POINTER(u64)]
+    L.ptx_fb_adaptive_passes.argtypes = [vp, C.POINTER(abi.PtxAdaptiveConfig), u32, u32, C.POINTER(u32), C.POINTER(u64)]
     L.ptx_fb_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
     L.ptx_fb_read.argtypes = [vp, vp, vp, vp]
     L.ptx_fb_read_mean.argtypes = [vp, vp]
@@ -193,6 +194,21 @@ class HipRenderLoop:
         self._check(self.L.ptx_fb_adaptive_pass(self._h, C.byref(cfg), renderer.max_bounces, C.byref(n)), "ptx_fb_adaptive_pass")
         return int(n.value)
 
+    def render_adaptive_passes(self, scene, camera, renderer, framebuffer, config, max_passes):
+        """`render_adaptive_pass` up to `max_passes` times, stopping after the first pass that finds nothing noisy
+        (app.rs:195-236) — same accumulators bit for bit, but several passes are traced together on the device
+        (`ptx_fb_adaptive_passes`).  Returns (passes that rendered something, samples added)."""
+        self._bind(scene, camera)
+        framebuffer._require(self)
+        mx = config.max_samples_per_pass
+        if mx is None:
+            mx = framebuffer.width * framebuffer.height
+        cfg = abi.PtxAdaptiveConfig(config.min_samples, config.variance_threshold, mx)
+        passes, n = C.c_uint32(0), C.c_uint64(0)
+        self._check(self.L.ptx_fb_adaptive_passes(self._h, C.byref(cfg), renderer.max_bounces, max_passes, C.byref(passes), C.byref(n)),
+                    "ptx_fb_adaptive_passes")
+        return int(passes.value), int(n.value)
+
     # -- one whole frame: run_benchmark's `for sample` loop (main.rs:123-141) / app.rs:195-236 ----
     def render_frame(self, scene, camera, renderer, width, height, spp, adaptive=None, max_spp=0):
         """Returns (mean image h x w x 3, counts h x w, stats dict).  The framebuffer the call uses is the context's
@@ -293,28 +309,23 @@ def combine_framebuffers(dist, buffers):
 def render_frame_distributed(all_reduce_max, loop, fb, scene, camera, renderer, spp, adaptive=None, max_spp=0):
     """One rank's share of `ptx_render_frame` when the frame is split over several GPUs (`loop.set_partition`).
 
-    Uniform passes need no communication.  The adaptive phase (app.rs:195-236) does not either, except for its stop
-    rule: a pixel's sample sequence depends only on its own sums (it is sampled in a pass iff it is noisy then), and
-    every rank selects the noisy pixels among its own interleaved 8x8 tiles — that selection IS the variance-driven
-    redistribution, tile interleave spreads noisy regions over the ranks — so ranks run their passes independently.
-    Only "stop when any pixel has max_spp samples" is global: one 4-byte all-reduce(MAX) per pass
-    (`all_reduce_max(int) -> int`; torch.distributed over RCCL on GPUs, gloo or a stub in tests).  A rank whose pixels
-    have converged keeps answering the collective with an empty pass.  Afterwards `combine_framebuffers` merges the
-    ranks' buffers; the result is bit-identical to the single-GPU frame.  Returns this rank's adaptive sample count."""
+    Uniform passes need no communication, and neither does the adaptive phase (app.rs:195-236): a pixel's sample
+    sequence depends only on its own sums (it is sampled in a pass iff it is noisy then), every rank selects the noisy
+    pixels among its own interleaved 8x8 tiles — that selection IS the variance-driven redistribution, the interleave
+    spreads noisy regions over the ranks — and the global stop rule "no pixel beyond max_spp samples" is a cap of
+    `max_spp - spp` passes on every rank, because all pixels start the adaptive phase with `spp` samples.  So each rank
+    runs `render_adaptive_passes` on its own and the only collective is one 4-byte all-reduce(MAX) of the pass count
+    for the frame statistics (`all_reduce_max(int) -> int`; torch.distributed over RCCL on GPUs, gloo or a stub in
+    tests).  Afterwards `combine_framebuffers` merges the ranks' buffers; the result is bit-identical to the single-GPU
+    frame.  Returns (this rank's adaptive sample count, adaptive passes of the whole frame)."""
     fb._require(loop)
     fb.reset()
     fb.render_passes(scene, camera, renderer, 0, spp)
-    rendered = 0
-    if adaptive is not None and max_spp:
-        while True:
-            mx = all_reduce_max(fb.stats()[1])
-            if mx >= max_spp:
-                break
-            n = loop.render_adaptive_pass(scene, camera, renderer, fb, adaptive)
-            rendered += n
-            if all_reduce_max(n) == 0:
-                break
-    return rendered
+    rendered, passes = 0, 0
+    if adaptive is not None and max_spp > spp:
+        passes, rendered = loop.render_adaptive_passes(scene, camera, renderer, fb, adaptive, max_spp - spp)
+        passes = all_reduce_max(passes)
+    return rendered, passes
 
 
 class DeviceFramebuffer:

@@ -290,9 +290,10 @@ def test_device_tonemap_srgb8(pkg, loop, oracle_det, scenes):
 
 
 def test_adaptive_frame_split_over_ranks_is_the_single_gpu_frame(pkg, loop, scenes):
-    """BASELINE config 5 on several GPUs: every rank runs uniform + adaptive passes on its interleaved tiles, sharing
-    only the stop rule (one all-reduce(MAX) per pass); the combined buffers equal the 1-GPU frame bit for bit.  Three
-    virtual ranks = three contexts on this GPU, one thread each, a barrier standing in for the collective."""
+    """BASELINE config 5 on several GPUs: every rank runs uniform + adaptive passes on its interleaved tiles on its own
+    (the pass cap is the same everywhere; one all-reduce(MAX) of the pass count for the statistics); the combined
+    buffers equal the 1-GPU frame bit for bit.  Three virtual ranks = three contexts on this GPU, one thread each, a
+    barrier standing in for the collective."""
     import threading
     sc = scenes("cornell", 1, 1.0)
     w, h, spp, cap, world = 72, 40, 5, 11, 3
@@ -313,7 +314,8 @@ def test_adaptive_frame_split_over_ranks_is_the_single_gpu_frame(pkg, loop, scen
             lp = pkg.HipRenderLoop(0)
             lp.set_partition(r, world)
             fb = pkg.DeviceFramebuffer(lp, w, h, adaptive=True)
-            pkg.render.render_frame_distributed(all_reduce_max, lp, fb, sc, cam, pkg.PathTracer(8), spp, adaptive=cfg, max_spp=cap)
+            _, passes = pkg.render.render_frame_distributed(all_reduce_max, lp, fb, sc, cam, pkg.PathTracer(8), spp, adaptive=cfg, max_spp=cap)
+            assert passes == stats["adaptive_passes"]
             parts[r] = fb.read()
         except Exception as e:   # pragma: no cover
             errors.append(e)
@@ -405,6 +407,51 @@ def test_nodes_wider_than_four_children(pkg, oracle_det, name, detail, flags):
     img_g = loop.render_pass(sc, cam, pkg.PathTracer(4), w, h, 1)
     img_c = osc.render_pass(cam, w, h, 1, 4)
     assert np.array_equal(bits(img_g), bits(img_c))
+
+
+@pytest.mark.parametrize("name,flags,detail,batch", [("cornell", 1, 1.0, 3), ("sponza_like", 3, 0.05, 4), ("cornell", 0, 1.0, 16)])
+def test_adaptive_passes_in_flight_equal_one_pass_at_a_time(pkg, scenes, monkeypatch, name, flags, detail, batch):
+    """ptx_fb_adaptive_passes traces several adaptive passes together and replays them per pixel; sums, squares, counts,
+    pass and sample totals must equal the render_adaptive_pass loop bit for bit (pixels that converge inside a batch
+    drop their speculative samples)."""
+    sc = scenes(name, flags, detail)
+    w, h, spp, max_passes = 80, 45, 5, 7
+    cam = sc.default_camera(w / h)
+    cfg = pkg.AdaptiveSamplingConfig(min_samples=6, variance_threshold=0.04)
+    r = pkg.PathTracer(8)
+    monkeypatch.setenv("PTX_ADAPTIVE_BATCH", str(batch))
+    lp = pkg.HipRenderLoop(0)                      # reads PTX_ADAPTIVE_BATCH at creation
+    fb = pkg.DeviceFramebuffer(lp, w, h, adaptive=True)
+    fb.render_passes(sc, cam, r, 0, spp)
+    passes, samples = lp.render_adaptive_passes(sc, cam, r, fb, cfg, max_passes)
+    got = fb.read()
+    monkeypatch.setenv("PTX_ADAPTIVE_BATCH", "1")
+    lp1 = pkg.HipRenderLoop(0)
+    fb1 = pkg.DeviceFramebuffer(lp1, w, h, adaptive=True)
+    fb1.render_passes(sc, cam, r, 0, spp)
+    p1 = s1 = 0
+    per_pass = []
+    for _ in range(max_passes):
+        n = lp1.render_adaptive_pass(sc, cam, r, fb1, cfg)
+        if n == 0:
+            break
+        p1 += 1
+        s1 += n
+        per_pass.append(n)
+    want = fb1.read()
+    assert (passes, samples) == (p1, s1) and p1 >= 3
+    assert per_pass[0] == w * h and per_pass[-1] < per_pass[1], per_pass      # pixels do converge inside the batches
+    assert np.array_equal(got[2], want[2]) and np.array_equal(bits(got[0]), bits(want[0])) and np.array_equal(bits(got[1]), bits(want[1]))
+    # counters on: one pass at a time, same result, and the counted primaries are the samples added
+    fb.reset()
+    fb.render_passes(sc, cam, r, 0, spp)
+    lp.set_counting(True)
+    lp.reset_counters()
+    assert lp.render_adaptive_passes(sc, cam, r, fb, cfg, max_passes) == (p1, s1)
+    assert lp.counters()["primary_rays"] == s1
+    lp.set_counting(False)
+    again = fb.read()
+    assert np.array_equal(again[2], want[2]) and np.array_equal(bits(again[0]), bits(want[0]))
 
 
 def test_passes_in_flight_do_not_change_the_sums(pkg, loop, scenes, monkeypatch):

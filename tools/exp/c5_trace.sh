@@ -1,0 +1,22 @@
+set -u
+OUT=$PWD/gpurun_out/prof_c5
+mkdir -p "$OUT"; export TMPDIR=/tmp
+cd "$PWD"
+timeout -s KILL 400 rocprofv3 --kernel-trace -d "$OUT/trace" --output-format csv -- python3 tools/exp/c5_anatomy.py > "$OUT/trace.log" 2>&1
+echo rc=$?
+python3 - <<'PY'
+import csv, glob, re
+f = glob.glob("gpurun_out/prof_c5/trace/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+# last adaptive pass = after the last k_noise_keys
+idx = max(i for i, r in enumerate(rows) if "k_noise_keys" in r["Kernel_Name"])
+t_prev = None
+out = open("gpurun_out/prof_c5/last_pass.txt", "w")
+for r in rows[idx:]:
+    m = re.search(r"(k_[a-z_]+)", r["Kernel_Name"]); name = m.group(1) if m else r["Kernel_Name"][:30]
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    gap = (s - t_prev) / 1e3 if t_prev else 0.0
+    out.write(f"{name:18s} dur {(e - s) / 1e3:9.1f} us  gap {gap:8.1f} us  grid {r.get('Grid_Size_X', r.get('Grid_Size',''))}\n")
+    t_prev = e
+out.close()
+PY

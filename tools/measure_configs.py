@@ -26,7 +26,10 @@ def main():
     pkg = ge.load_package()
     cpu_s = float(os.environ.get("CPU_SECONDS", "8"))
     rows = []
+    only = os.environ.get("ONLY")          # e.g. ONLY=C5: one row
     for name, scene_name, detail, flags, w, h, spp, bounces, adaptive in CONFIGS:
+        if only and not name.startswith(only):
+            continue
         t0 = time.time()
         scene = pkg.Scene.procedural(scene_name, 1, detail, flags)
         build_s = time.time() - t0
