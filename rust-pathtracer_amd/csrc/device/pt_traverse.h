@@ -225,12 +225,12 @@ struct Traverser {
     // FOUR = false: no lane of this run has a 4-child record (the reference's builder never makes one; they only
     // come from the chains built for wider nodes), so the fourth child's loads, test and push terms are compiled out.
     template <bool EXACT, bool FOUR>
-    PT_DEV void do_node(const SceneDev& S, const StackRef& st, LaneCnt& lc, uint32_t& err) {
+    PT_DEV void do_node(const SceneDev& S, const StackRef& st, LaneCnt& lc, uint32_t& err, const float4 a0, const float4 a1,
+                        const float4 b0, const float4 b1, const float4 c0, const float4 c1) {
         const float tmin = RAY_EPSILON;
         const uint32_t nchild = ((pw >> NODE_NCHILD_SHIFT) & 3u) + 1u;
         const float4* p = reinterpret_cast<const float4*>(&S.nodes[pw & NODE_INDEX_MASK]);
-        // children 0..2 are read unconditionally (unused slots of a record are zero)
-        const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3], c0 = p[4], c1 = p[5];
+        // children 0..2 were fetched by the caller (unused slots of a record are zero)
         float4 d0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d1 = d0;
         if (FOUR && nchild > 3u) { d0 = p[6]; d1 = p[7]; }
         if (CNT) {
@@ -264,10 +264,8 @@ struct Traverser {
     }
 
     // ---- ACT_TRI: intersect_triangle on the next primitive of the leaf ------------------
-    PT_DEV void do_tri(const SceneDev& S, LaneCnt& lc) {
+    PT_DEV void do_tri(LaneCnt& lc, const float4 ta, const float4 tb, const float4 tc) {
         const float tmin = RAY_EPSILON;
-        const float4* p = reinterpret_cast<const float4*>(&S.tris[pw]);
-        const float4 ta = p[0], tb = p[1], tc = p[2];
         if (CNT) { lc.prim_reads++; lc.tri_tests++; }
         pw += 1u; tri_cnt -= 1u;
         if (tri_cnt == 0u) act = ACT_POP;
@@ -422,18 +420,24 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
         if (ce == mx || ce >= TH_ENTER) {
             if (tv.act == ACT_ENTER) tv.do_enter(S, st, lc);
         }
-        if (ctn == mx || ctn >= TH_TRI) {
-            if (tv.act == ACT_TRI) tv.do_tri(S, lc);
+        // Triangle and node lanes fetch their records together and wait once: the two sections used to pay one
+        // memory round trip each, and a wave spends more time waiting on these loads than issuing.
+        const bool f_tri = (ctn == mx || ctn >= TH_TRI) && tv.act == ACT_TRI;
+        const bool f_node = (cn == mx || cn >= TH_NODE) && tv.act == ACT_NODE;
+        // wave-uniform choice of the node-visit variant: x86 NaN rule only if some lane can produce NaNs,
+        // fourth child only if some lane's record has one
+        const bool wave_special = __ballot(f_node && (tv.exact || (tv.pw >> NODE_NCHILD_SHIFT) == 3u)) != 0ull;
+        float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
+        if (f_tri || f_node) {
+            const float4* p = f_node ? reinterpret_cast<const float4*>(&S.nodes[tv.pw & NODE_INDEX_MASK])
+                                     : reinterpret_cast<const float4*>(&S.tris[tv.pw]);
+            r0 = p[0]; r1 = p[1]; r2 = p[2];
+            if (f_node) { r3 = p[3]; r4 = p[4]; r5 = p[5]; }
         }
-        if (cn == mx || cn >= TH_NODE) {
-            // wave-uniform choice of the node-visit variant: x86 NaN rule only if some lane can produce NaNs,
-            // fourth child only if some lane's record has one
-            const bool is_node = tv.act == ACT_NODE;
-            const bool wave_special = __ballot(is_node && (tv.exact || (tv.pw >> NODE_NCHILD_SHIFT) == 3u)) != 0ull;
-            if (is_node) {
-                if (wave_special) tv.template do_node<true, true>(S, st, lc, err);
-                else tv.template do_node<false, false>(S, st, lc, err);
-            }
+        if (f_tri) tv.do_tri(lc, r0, r1, r2);
+        if (f_node) {
+            if (wave_special) tv.template do_node<true, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
+            else tv.template do_node<false, false>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
         }
     }
 }
