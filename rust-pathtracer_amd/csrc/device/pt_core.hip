@@ -137,6 +137,7 @@ PT_DEV void flush_lane_cnt(DevCounters* dc, const LaneCnt& lc, uint32_t rays, bo
 // ---- ray batches (ptx_trace_batch) ------------------------------------------------
 struct BatchSrc {
     const PtxRay* rays;
+    PT_DEV uint32_t key(uint32_t i) const { return i; }
     PT_DEV void fetch(uint32_t i, V3* o, V3* d, float* tmax) const {
         const PtxRay r = rays[i];
         *o = v3(r.origin[0], r.origin[1], r.origin[2]);
@@ -213,17 +214,15 @@ __global__ void k_raygen(SceneDev S, CameraDev cam, PathArrays P, const uint32_t
 struct ExtendSrc {
     const PathArrays& P;
     const uint32_t* q;
-    PT_DEV void fetch(uint32_t i, V3* o, V3* d, float* tmax) const {
-        const uint32_t p = q[i];
+    PT_DEV uint32_t key(uint32_t i) const { return q[i]; }     // the path slot
+    PT_DEV void fetch(uint32_t p, V3* o, V3* d, float* tmax) const {
         const float4 ro = P.ray_o[p], rd = P.ray_d[p];
         *o = v3(ro.x, ro.y, ro.z); *d = v3(rd.x, rd.y, rd.z); *tmax = ro.w;
     }
 };
 struct ExtendSink {
     const PathArrays& P;
-    const uint32_t* q;
-    PT_DEV void hit(uint32_t i, uint32_t inst, uint32_t tri, float t, float u, float v) const {
-        const uint32_t p = q[i];
+    PT_DEV void hit(uint32_t p, uint32_t inst, uint32_t tri, float t, float u, float v) const {
         P.hit[p] = make_float4(t, u, v, __uint_as_float(inst));
         P.hit_tri[p] = tri;
     }
@@ -238,7 +237,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S
     LaneCnt lc = {0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, e = 0;
     ExtendSrc src{P, q};
-    ExtendSink sink{P, q};
+    ExtendSink sink{P};
     trace_queue<false, CNT>(S, st, &ctr->w_extend, ctr->n_active, src, sink, lc, nrays, e);
     if (e) atomicOr(err, e);
     if (CNT) flush_lane_cnt(dc, lc, nrays, false);
@@ -249,8 +248,8 @@ struct ShadowSrc {
     const SceneDev& S;
     const PathArrays& P;
     const uint32_t* qs;
-    PT_DEV void fetch(uint32_t i, V3* o, V3* d, float* tmax) const {
-        const uint32_t entry = qs[i];
+    PT_DEV uint32_t key(uint32_t i) const { return qs[i]; }    // path slot * 2 + (0 sun, 1 sky)
+    PT_DEV void fetch(uint32_t entry, V3* o, V3* d, float* tmax) const {
         const uint32_t p = entry >> 1;
         const float4 so = P.sh_o[p];
         *o = v3(so.x, so.y, so.z);
@@ -261,11 +260,9 @@ struct ShadowSrc {
 };
 struct ShadowSink {
     const PathArrays& P;
-    const uint32_t* qs;
     PT_DEV void hit(uint32_t, uint32_t, uint32_t, float, float, float) const {}
-    PT_DEV void done(uint32_t i, bool found) const {
+    PT_DEV void done(uint32_t entry, bool found) const {
         if (!found) return;   // unoccluded: the pending contribution stands
-        const uint32_t entry = qs[i];
         const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if ((entry & 1u) == 0u) P.c_sun[entry >> 1] = z; else P.c_sky[entry >> 1] = z;
     }
@@ -277,7 +274,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_shadow(SceneDev S
     LaneCnt lc = {0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, e = 0;
     ShadowSrc src{S, P, qs};
-    ShadowSink sink{P, qs};
+    ShadowSink sink{P};
     trace_queue<true, CNT>(S, st, &ctr->w_shadow, ctr->n_shadow, src, sink, lc, nrays, e);
     if (e) atomicOr(err, e);
     if (CNT) flush_lane_cnt(dc, lc, nrays, true);

@@ -361,8 +361,9 @@ struct Traverser {
     }
 };
 
-// Wave-persistent driver.  `Src::fetch(i, o, d, tmax)` loads queue entry i; `Sink::hit(i, inst, tri, t, u, v)` records
-// an accepted closest hit (the last call for an entry is its result); `Sink::done(i, found)` ends the entry.
+// Wave-persistent driver.  `Src::key(i)` turns queue position i into the entry's key k (read once, kept in a register);
+// `Src::fetch(k, o, d, tmax)` loads its ray; `Sink::hit(k, inst, tri, t, u, v)` records an accepted closest hit (the last
+// call for an entry is its result); `Sink::done(k, found)` ends the entry.
 // `work` is the queue's shared cursor, `n` its length.
 template <bool ANY, bool CNT, class Src, class Sink>
 PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink,
@@ -392,9 +393,9 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
                 if (i < n) {
                     V3 o, d;
                     float tmax;
-                    src.fetch(i, &o, &d, &tmax);
+                    my = src.key(i);             // what fetch / hit / done address the entry by (e.g. its path slot)
+                    src.fetch(my, &o, &d, &tmax);
                     tv.begin(S, o, d, tmax);
-                    my = i;
                     nrays++;
                 }
             }
