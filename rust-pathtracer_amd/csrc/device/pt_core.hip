@@ -56,7 +56,8 @@ struct PathArrays {
 };
 
 // per-iteration counter block
-struct IterCtr { uint32_t n_active, n_shadow, n_final, w_extend, w_shadow, pad0, pad1, pad2; };
+// (the queue cursors are arrays: one per queue segment, see trace_queue)
+struct IterCtr { uint32_t n_active, n_shadow, n_final, pad0; uint32_t w_extend[QUEUE_SEGMENTS], w_shadow[QUEUE_SEGMENTS]; };
 constexpr uint32_t MAX_ITERS = 4096;
 
 constexpr int TRACE_GRID = 256 * 4 * PT_WAVES_PER_SIMD;   // persistent waves, PT_WAVES_PER_SIMD per SIMD: the VGPR and LDS budget
@@ -173,14 +174,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(Scene
 // ---- ray-gen: render_pixel up to renderer.render (renderloop/parallel.rs:31-56) ----
 __global__ void k_raygen(SceneDev S, CameraDev cam, PathArrays P, const uint32_t* wl_pixel, const uint32_t* wl_sample,
                          const uint32_t* fb_counts, uint32_t uniform_sample, uint32_t n, uint32_t width, uint32_t height,
-                         uint32_t* q, IterCtr* ctr0, uint32_t aov, PtxRay* out_rays, uint32_t stride) {
+                         uint32_t* q, IterCtr* ctr0, uint32_t aov, PtxRay* out_rays, uint32_t batch) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && ctr0) ctr0->n_active = n;
     if (i >= n) return;
-    // stride != 0: slots [k*stride, (k+1)*stride) are sample uniform_sample + k of the same `stride` pixels
-    const uint32_t pixel = wl_pixel[stride ? i % stride : i];
-    // sample index: explicit list (render_pixels), the pixel's own count (adaptive), or the pass's; + k for slot block k
-    const uint32_t sample_index = wl_sample ? wl_sample[i] : (fb_counts ? fb_counts[pixel] : uniform_sample) + (stride ? i / stride : 0u);
+    // batch > 1: slots [j*batch, (j+1)*batch) are `batch` consecutive samples of work-list pixel j (pixel-major, so a
+    // stretch of the queue is a region of the image)
+    const uint32_t j = batch > 1u ? i / batch : i, k = batch > 1u ? i - j * batch : 0u;
+    const uint32_t pixel = wl_pixel[j];
+    // sample index: explicit list (render_pixels), the pixel's own count (adaptive), or the pass's; + k within a batch
+    const uint32_t sample_index = wl_sample ? wl_sample[i] : (fb_counts ? fb_counts[pixel] : uniform_sample) + k;
     const uint32_t x = pixel % width, y = pixel / width;
     float px, py, lx, ly;
     bluenoise_sample(S.bn_pixel, S.bn_size, x, y, sample_index, &px, &py);
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S
     uint32_t nrays = 0, e = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
-    trace_queue<false, CNT>(S, st, &ctr->w_extend, ctr->n_active, src, sink, lc, nrays, e);
+    trace_queue<false, CNT>(S, st, ctr->w_extend, ctr->n_active, src, sink, lc, nrays, e);
     if (e) atomicOr(err, e);
     if (CNT) flush_lane_cnt(dc, lc, nrays, false);
 }
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_shadow(SceneDev S
     uint32_t nrays = 0, e = 0;
     ShadowSrc src{S, P, qs};
     ShadowSink sink{P};
-    trace_queue<true, CNT>(S, st, &ctr->w_shadow, ctr->n_shadow, src, sink, lc, nrays, e);
+    trace_queue<true, CNT>(S, st, ctr->w_shadow, ctr->n_shadow, src, sink, lc, nrays, e);
     if (e) atomicOr(err, e);
     if (CNT) flush_lane_cnt(dc, lc, nrays, true);
 }
@@ -748,16 +751,16 @@ __global__ void k_finalize(PathArrays P, const uint32_t* q_final, const IterCtr*
 }
 
 // ---- several passes in flight: add each pixel's samples in pass order (main.rs:131-137 / framebuffer.rs:44-50) ----
-__global__ void k_accumulate_batch(PathArrays P, const uint32_t* wl_pixel, uint32_t stride, uint32_t batch, Target tg) {
+__global__ void k_accumulate_batch(PathArrays P, const uint32_t* wl_pixel, uint32_t n_pixels, uint32_t batch, Target tg) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= stride) return;
+    if (slot >= n_pixels) return;
     const uint32_t pixel = wl_pixel[slot];
     const size_t f = (size_t)pixel * 3;
     float sx = tg.sum[f], sy = tg.sum[f + 1], sz = tg.sum[f + 2];
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
     if (tg.sum_sq) { qx = tg.sum_sq[f]; qy = tg.sum_sq[f + 1]; qz = tg.sum_sq[f + 2]; }
     for (uint32_t k = 0; k < batch; ++k) {
-        const float4 c = P.rad[(size_t)k * stride + slot];
+        const float4 c = P.rad[(size_t)slot * batch + k];
         sx += c.x; sy += c.y; sz += c.z;
         qx += c.x * c.x; qy += c.y * c.y; qz += c.z * c.z;
     }
@@ -819,7 +822,7 @@ __global__ void k_noise_keys(const uint32_t* owned, uint32_t n, const float* sum
         if ((threadIdx.x & 63u) == 0u && m) atomicAdd(n_noisy, (uint32_t)__popcll(m));
     }
 }
-// `batch` adaptive passes traced together for the `n` pixels of `work`: slot k*n + i holds the sample the pixel would
+// `batch` adaptive passes traced together for the `n` pixels of `work`: slot i*batch + k holds the sample the pixel would
 // get in pass k IF it is still noisy then (sample_index = its count, parallel.rs:109-114).  A pixel's sums change only
 // when it is sampled, so replaying the passes per pixel — add sample k, stop at the first pass that finds the pixel
 // converged, drop the rest — leaves sum / sum_sq / count exactly as `batch` separate passes would.
@@ -837,7 +840,7 @@ __global__ void k_accumulate_adaptive(PathArrays P, const uint32_t* work, uint32
         for (uint32_t k = 0; k < batch; ++k) {
             float err;
             if (!pixel_noisy(count, s1, s2, min_samples, threshold, &err)) break;
-            const float4 c = P.rad[(size_t)k * n + i];
+            const float4 c = P.rad[(size_t)i * batch + k];
             s1 = v3(s1.x + c.x, s1.y + c.y, s1.z + c.z);
             s2 = v3(s2.x + c.x * c.x, s2.y + c.y * c.y, s2.z + c.z * c.z);
             count += 1u;
@@ -1239,7 +1242,7 @@ static int32_t check_device_error(PtxContext* ctx) {
 // Trace n path slots that k_raygen is about to initialise from (wl_pixel, wl_sample | fb counts | uniform).
 static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32_t* wl_sample, const uint32_t* per_pixel_counts,
                          uint32_t uniform_sample, uint32_t n, uint32_t w, uint32_t h, uint32_t max_bounces, const Target& tg, bool aov,
-                         uint32_t stride = 0) {
+                         uint32_t batch = 0) {
     if (n == 0) return PTX_OK;
     int32_t st = ensure_capacity(ctx, n);
     if (st != PTX_OK) return st;
@@ -1249,7 +1252,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
     {
         ScopedEvent ev(ctx, CLS_RAYGEN);
         hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->cam, ctx->P, wl_pixel, wl_sample,
-                           per_pixel_counts, uniform_sample, n, w, h, ctx->q[0], ctx->ctrs, aov ? 1u : 0u, (PtxRay*)nullptr, stride);
+                           per_pixel_counts, uniform_sample, n, w, h, ctx->q[0], ctx->ctrs, aov ? 1u : 0u, (PtxRay*)nullptr, batch);
     }
     const int trace_grid = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
     const int shade_grid = (int)std::min<uint64_t>(256 * 8, (n + SHADE_BLOCK - 1) / SHADE_BLOCK);
@@ -1697,7 +1700,7 @@ int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t co
         } else {
             Target deferred = tg;
             deferred.defer = 1u;
-            st = run_paths(ctx, ctx->wl_pixel, nullptr, nullptr, first_sample + k, n1 * b, ctx->fb_w, ctx->fb_h, max_bounces, deferred, false, n1);
+            st = run_paths(ctx, ctx->wl_pixel, nullptr, nullptr, first_sample + k, n1 * b, ctx->fb_w, ctx->fb_h, max_bounces, deferred, false, b);
             if (st != PTX_OK) return st;
             ScopedEvent ev(ctx, CLS_ACCUM);
             hipLaunchKernelGGL(k_accumulate_batch, dim3((n1 + 255) / 256), dim3(256), 0, ctx->stream, ctx->P, ctx->wl_pixel, n1, b, tg);
@@ -1809,7 +1812,7 @@ int32_t ptx_fb_adaptive_passes(PtxContext* ctx, const PtxAdaptiveConfig* cfg, ui
         tg.sum = ctx->fb_sum; tg.sum_sq = ctx->fb_sum_sq; tg.counts = ctx->fb_counts;
         Target deferred = tg;
         deferred.defer = 1u;
-        st = run_paths(ctx, work, nullptr, ctx->fb_counts, 0, n_noisy * b, ctx->fb_w, ctx->fb_h, max_bounces, deferred, false, n_noisy);
+        st = run_paths(ctx, work, nullptr, ctx->fb_counts, 0, n_noisy * b, ctx->fb_w, ctx->fb_h, max_bounces, deferred, false, b);
         if (st != PTX_OK) return st;
         HIPCHK(hipMemsetAsync(d_count, 0, sizeof(IterCtr), ctx->stream));
         {
@@ -1934,7 +1937,7 @@ int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t
     do {
         if (hipMemcpyAsync(d_rays, rays, n * sizeof(PtxRay), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = fail(ctx, PTX_ERR_HIP, "H2D copy failed"); break; }
         const int grid = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
-        uint32_t* d_work = &ctx->ctrs[MAX_ITERS - 3].w_extend;   // spare counter block as the batch cursor
+        uint32_t* d_work = ctx->ctrs[MAX_ITERS - 3].w_extend;   // spare counter block as the batch cursor
         if (hipMemsetAsync(&ctx->ctrs[MAX_ITERS - 3], 0, sizeof(IterCtr), ctx->stream) != hipSuccess) { st = fail(ctx, PTX_ERR_HIP, "memset failed"); break; }
         ScopedEvent* ev = new ScopedEvent(ctx, mode == PTX_TRACE_ANY ? CLS_SHADOW : CLS_EXTEND);
         if (mode == PTX_TRACE_ANY) {

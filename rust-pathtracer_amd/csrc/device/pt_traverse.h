@@ -102,6 +102,15 @@ constexpr uint32_t MARK_EXACT = 0x01000000u;
 // no flat pointers into LDS).  Every kernel that traverses gets its own copy.
 static __shared__ uint2 s_stack[LDS_STACK * TRACE_BLOCK];
 
+// A queue is cut into QUEUE_SEGMENTS contiguous stretches with one cursor each.  Blocks b and b + 8 share an XCD (and
+// its L2), so a block starts on segment b % 8 and the rays an XCD traces come from one stretch of the queue — one
+// region of the image while the queue is still close to pixel order — instead of from all over it; a wave that finds
+// its segment drained moves on to the next one, so placement only matters for speed.
+#ifndef PT_QUEUE_SEGMENTS
+#define PT_QUEUE_SEGMENTS 8
+#endif
+constexpr uint32_t QUEUE_SEGMENTS = PT_QUEUE_SEGMENTS;
+
 struct StackRef {
     uint2* ovf;            // &ovf[0][global_lane], entry stride = ovf_stride
     uint32_t ovf_stride;
@@ -368,6 +377,9 @@ struct Traverser {
 template <bool ANY, bool CNT, class Src, class Sink>
 PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink,
                         LaneCnt& lc, uint32_t& nrays, uint32_t& err) {
+    // a short queue cannot feed every wave: the surplus ones leave without touching the cursors (6144 waves bumping
+    // a few addresses made an empty launch cost 70 us)
+    if ((unsigned long long)(blockIdx.x / QUEUE_SEGMENTS) * 16ull >= (unsigned long long)n / QUEUE_SEGMENTS + 16ull) return;
     Traverser<ANY, CNT> tv;
     tv.act = ACT_IDLE;
     tv.exact = false; tv.in_mesh = false; tv.found = false;
@@ -379,18 +391,21 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
     // and entries parked in 6144 waves' prefetch slots lengthen its tail by more than the hidden atomic saves.)
     bool exhausted = false;   // wave-uniform
     const uint32_t lane = threadIdx.x & 63u;
+    uint32_t seg = blockIdx.x % QUEUE_SEGMENTS, seg_left = QUEUE_SEGMENTS;   // wave-uniform
     for (;;) {
         const unsigned long long idle = __ballot(tv.act == ACT_IDLE);
         if (!exhausted && (uint32_t)__popcll(idle) >= (ANY ? REFILL_MIN_IDLE_ANY : REFILL_MIN_IDLE)) {
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             const int leader = __ffsll((long long)idle) - 1;
+            const uint32_t lo = (uint32_t)(((unsigned long long)n * seg) / QUEUE_SEGMENTS);
+            const uint32_t hi = (uint32_t)(((unsigned long long)n * (seg + 1u)) / QUEUE_SEGMENTS);
             uint32_t basei = 0;
-            if ((int)lane == leader) basei = atomicAdd(work, n_idle);
-            basei = __shfl(basei, leader);
+            if ((int)lane == leader) basei = atomicAdd(&work[seg], n_idle);
+            basei = lo + __shfl(basei, leader);
             if (tv.act == ACT_IDLE) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t i = basei + rank;
-                if (i < n) {
+                if (i < hi) {
                     V3 o, d;
                     float tmax;
                     my = src.key(i);             // what fetch / hit / done address the entry by (e.g. its path slot)
@@ -399,7 +414,10 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
                     nrays++;
                 }
             }
-            if (basei + n_idle >= n) exhausted = true;
+            if (basei + n_idle >= hi) {          // this segment is drained: on to the next, or done after all of them
+                seg = (seg + 1u) % QUEUE_SEGMENTS;
+                if (--seg_left == 0u) exhausted = true;
+            }
         }
         if (tv.act == ACT_POP) tv.pop(st);
         if (tv.act == ACT_DONE) { sink.done(my, tv.found); tv.act = ACT_IDLE; }
