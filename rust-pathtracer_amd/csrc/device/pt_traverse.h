@@ -106,10 +106,15 @@ static __shared__ uint2 s_stack[LDS_STACK * TRACE_BLOCK];
 // its L2), so a block starts on segment b % 8 and the rays an XCD traces come from one stretch of the queue — one
 // region of the image while the queue is still close to pixel order — instead of from all over it; a wave that finds
 // its segment drained moves on to the next one, so placement only matters for speed.
-#ifndef PT_QUEUE_SEGMENTS
-#define PT_QUEUE_SEGMENTS 8
+#ifndef PT_QUEUE_SEGMENT_SHIFT
+#define PT_QUEUE_SEGMENT_SHIFT 3
 #endif
-constexpr uint32_t QUEUE_SEGMENTS = PT_QUEUE_SEGMENTS;
+#ifndef PT_SEGMENT_MIN_QUEUE
+#define PT_SEGMENT_MIN_QUEUE (8u << 20)
+#endif
+constexpr uint32_t QUEUE_SEGMENT_SHIFT = PT_QUEUE_SEGMENT_SHIFT;
+constexpr uint32_t QUEUE_SEGMENTS = 1u << QUEUE_SEGMENT_SHIFT;
+constexpr uint32_t SEGMENT_MIN_QUEUE = PT_SEGMENT_MIN_QUEUE;   // queues shorter than this use one cursor
 
 struct StackRef {
     uint2* ovf;            // &ovf[0][global_lane], entry stride = ovf_stride
@@ -379,7 +384,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
                         LaneCnt& lc, uint32_t& nrays, uint32_t& err) {
     // a short queue cannot feed every wave: the surplus ones leave without touching the cursors (6144 waves bumping
     // a few addresses made an empty launch cost 70 us)
-    if ((unsigned long long)(blockIdx.x / QUEUE_SEGMENTS) * 16ull >= (unsigned long long)n / QUEUE_SEGMENTS + 16ull) return;
+    if ((unsigned long long)blockIdx.x * 16ull >= (unsigned long long)n + 128ull) return;
     Traverser<ANY, CNT> tv;
     tv.act = ACT_IDLE;
     tv.exact = false; tv.in_mesh = false; tv.found = false;
@@ -391,14 +396,18 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
     // and entries parked in 6144 waves' prefetch slots lengthen its tail by more than the hidden atomic saves.)
     bool exhausted = false;   // wave-uniform
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t seg = blockIdx.x % QUEUE_SEGMENTS, seg_left = QUEUE_SEGMENTS;   // wave-uniform
+    // short queues keep one cursor: with few entries per wave the extra cursor traffic at the end of every segment
+    // costs more than the L2 affinity gains (Cornell 640x360: 7.8 ms per frame with one cursor, 9.3 with eight)
+    const uint32_t seg_shift = n >= SEGMENT_MIN_QUEUE ? QUEUE_SEGMENT_SHIFT : 0u, nseg = 1u << seg_shift;
+    const uint32_t seg_size = (n + nseg - 1u) >> seg_shift;   // n < 2^31
+    uint32_t seg = blockIdx.x & (nseg - 1u), seg_left = nseg;   // wave-uniform
     for (;;) {
         const unsigned long long idle = __ballot(tv.act == ACT_IDLE);
         if (!exhausted && (uint32_t)__popcll(idle) >= (ANY ? REFILL_MIN_IDLE_ANY : REFILL_MIN_IDLE)) {
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             const int leader = __ffsll((long long)idle) - 1;
-            const uint32_t lo = (uint32_t)(((unsigned long long)n * seg) / QUEUE_SEGMENTS);
-            const uint32_t hi = (uint32_t)(((unsigned long long)n * (seg + 1u)) / QUEUE_SEGMENTS);
+            const uint32_t lo = seg * seg_size;
+            const uint32_t hi = lo + seg_size < n ? lo + seg_size : n;
             uint32_t basei = 0;
             if ((int)lane == leader) basei = atomicAdd(&work[seg], n_idle);
             basei = lo + __shfl(basei, leader);
@@ -415,7 +424,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
                 }
             }
             if (basei + n_idle >= hi) {          // this segment is drained: on to the next, or done after all of them
-                seg = (seg + 1u) % QUEUE_SEGMENTS;
+                seg = (seg + 1u) & (nseg - 1u);
                 if (--seg_left == 0u) exhausted = true;
             }
         }

@@ -24,6 +24,8 @@ CONFIGS = [
 
 def main():
     pkg = ge.load_package()
+    if os.environ.get("PT_VARIANT_LIB"):      # kernel experiments only: a library built by tools/build_variant.sh
+        pkg.render.DEVICE_LIB_PATH = os.path.abspath(os.environ["PT_VARIANT_LIB"])
     cpu_s = float(os.environ.get("CPU_SECONDS", "8"))
     rows = []
     only = os.environ.get("ONLY")          # e.g. ONLY=C5: one row
@@ -56,7 +58,7 @@ def main():
         rays = cnt["rays_closest"] + cnt["rays_any"]
         primaries = stats["total_samples"]
         ab = pkg._abi.algorithmic_bytes(cnt, texel_bytes_per_lookup=48, adaptive=adaptive is not None)
-        cpu = bench.cpu_baseline(pkg, scene, cam, w, h, bounces, cpu_s)
+        cpu = bench.cpu_baseline(pkg, scene, cam, w, h, bounces, cpu_s) if cpu_s > 0 else {"cores": 0, "mprimary_per_s": 1e-9, "value": 0.0}
         rows.append({
             "config": name, "res_spp": f"{w}x{h} / {spp}" + (f" + adaptive to {cap}" if adaptive else ""),
             "triangles": scene.stats()["triangles"], "instances": scene.stats()["instances"], "scene_build_s": round(build_s, 2),
