@@ -68,12 +68,30 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render core has no CPU fallback")
+    # Rehearsal on a one-GPU box only (never the driver's launch): PTX_BENCH_DEVICE pins every rank to one card and
+    # PTX_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one GPU; the control flow is the same.
+    if os.environ.get("PTX_BENCH_DEVICE"):
+        local_rank = int(os.environ["PTX_BENCH_DEVICE"])
+    backend = os.environ.get("PTX_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL
+        else:
+            dist.init_process_group(backend=backend)
 
+    verbose = bool(os.environ.get("PTX_BENCH_VERBOSE"))
+
+    def note(msg):
+        if verbose:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    if verbose:
+        import faulthandler
+        faulthandler.dump_traceback_later(60, repeat=False, file=sys.stderr)
+    note("process group up" if world > 1 else "single rank")
     pkg = ge.load_package()
     if os.environ.get("PT_VARIANT_LIB"):      # kernel experiments only: a library built by tools/build_variant.sh
         pkg.render.DEVICE_LIB_PATH = os.path.abspath(os.environ["PT_VARIANT_LIB"])
@@ -87,6 +105,7 @@ def main():
     loop.set_partition(rank, world)
     fb = pkg.DeviceFramebuffer(loop, w, h, adaptive=True)
     loop._bind(scene, cam)   # upload once: inputs are resident in HBM before anything is timed
+    note(f"scene built in {build_s:.1f} s and uploaded")
 
     if world > 1:
         d_sum = torch.empty(h * w * 3, dtype=torch.float32, device="cuda")
@@ -99,7 +118,13 @@ def main():
         if world > 1:
             fb.export_dev(d_sum.data_ptr(), d_sq.data_ptr(), d_cnt.data_ptr())
             loop.sync()                       # library stream -> visible to torch's stream
-            pkg.render.combine_framebuffers(dist, (d_sum, d_sq, d_cnt))   # RCCL over xGMI: disjoint tiles + zeros => exact
+            if backend == "nccl":
+                pkg.render.combine_framebuffers(dist, (d_sum, d_sq, d_cnt))   # RCCL over xGMI: disjoint tiles + zeros => exact
+            else:                             # rehearsal: gloo reduces host copies
+                for t in (d_sum, d_sq, d_cnt):
+                    c = t.cpu()
+                    dist.all_reduce(c)
+                    t.copy_(c)
 
     def fence():
         loop.sync()
@@ -115,15 +140,19 @@ def main():
     fence()
     cnt = loop.counters()
     loop.set_counting(False)
+    note("counted frame done")
     if world > 1:
         keys = sorted(cnt)
-        t = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device="cuda")
+        t = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t)
         cnt = {k: int(v) for k, v in zip(keys, t.tolist())}
+        note("counters reduced")
 
     for _ in range(args.warmup):
         frame()
+        note("warm-up frame done")
     fence()
+    note("fenced")
     loop.set_profiling(True)
     loop.reset_timings()
     t0 = time.perf_counter()
@@ -131,10 +160,11 @@ def main():
         frame()
     fence()
     elapsed = time.perf_counter() - t0
+    note(f"timed region {elapsed:.3f} s")
     tim = loop.timings()
     loop.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
