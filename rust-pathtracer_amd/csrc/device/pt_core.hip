@@ -59,6 +59,10 @@ struct PathArrays {
 // (the queue cursors are arrays: one per queue segment, see trace_queue)
 struct IterCtr { uint32_t n_active, n_shadow, n_final, pad0; uint32_t w_extend[QUEUE_SEGMENTS], w_shadow[QUEUE_SEGMENTS]; };
 constexpr uint32_t MAX_ITERS = 4096;
+// P.rad[].w = pixel index | which pending contributions of the previous step are stored (an absent one is +0.0: it is
+// neither written nor read back, which is most of them — the BSDF-sampled sun term almost always, the NEE terms whenever
+// the light is below the surface)
+constexpr uint32_t PEND_SUN = 1u << 29, PEND_SKY = 1u << 30, PEND_POST = 1u << 31, PIXEL_MASK = (1u << 29) - 1u;
 
 constexpr int TRACE_GRID = 256 * 4 * PT_WAVES_PER_SIMD;   // persistent waves, PT_WAVES_PER_SIMD per SIMD: the VGPR and LDS budget
 #ifndef PT_SHADE_BLOCK
@@ -207,7 +211,6 @@ __global__ void k_raygen(SceneDev S, CameraDev cam, PathArrays P, const uint32_t
     P.rad[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(pixel));
     P.rng[i] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    P.c_sun[i] = z; P.c_sky[i] = z; P.c_post[i] = z;
     P.sample[i] = sample_index;
     if (aov) { P.aov_a[i] = z; P.aov_n[i] = z; }
     q[i] = i;
@@ -327,9 +330,14 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
             const bool has_hit = h_inst != PTX_MISS;
 
             // pending adds of the previous step, in the reference's order (NEE sun, NEE sky, BSDF-sampled sun)
-            { const float4 a = P.c_sun[p], b = P.c_sky[p], c = P.c_post[p];
+            { const uint32_t pend = __float_as_uint(ra4.w);
+              float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, c = a;
+              if (pend & PEND_SUN) a = P.c_sun[p];
+              if (pend & PEND_SKY) b = P.c_sky[p];
+              if (pend & PEND_POST) c = P.c_post[p];
               L = L + v3(a.x, a.y, a.z); L = L + v3(b.x, b.y, b.z); L = L + v3(c.x, c.y, c.z); }
             V3 c_sun = splat(0.0f), c_sky = splat(0.0f), c_post = splat(0.0f);
+            bool has_post = false;
             V3 sh_o = splat(0.0f), sh_d = splat(0.0f);
             alive = true;
             const V3 sun_dir = v3(S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]);
@@ -511,6 +519,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                                 if (S.sun_enabled && dot(new_dir, sun_dir) >= S.sun_cos_angle) {
                                     const float mis = mis_weight(pdf, S.sun_pdf);
                                     c_post = T * sun_color * mis;
+                                    has_post = true;
                                 }
                                 bounce++;
                             }
@@ -660,10 +669,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
 
             flags = (bounce & FL_BOUNCE_MASK) | (last_spec ? FL_SPECULAR : 0u) | (state << FL_STATE_SHIFT) |
                     (first_hit ? FL_FIRST_HIT : 0u) | ((step << FL_STEP_SHIFT) & FL_STEP_MASK);
-            P.rad[p] = make_float4(L.x, L.y, L.z, ra4.w);
-            P.c_sun[p] = make_float4(c_sun.x, c_sun.y, c_sun.z, 0.0f);
-            P.c_sky[p] = make_float4(c_sky.x, c_sky.y, c_sky.z, 0.0f);
-            P.c_post[p] = make_float4(c_post.x, c_post.y, c_post.z, 0.0f);
+            const uint32_t pend_next = (push_sun ? PEND_SUN : 0u) | (push_sky ? PEND_SKY : 0u) | (has_post ? PEND_POST : 0u);
+            P.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float((__float_as_uint(ra4.w) & PIXEL_MASK) | pend_next));
+            if (push_sun) P.c_sun[p] = make_float4(c_sun.x, c_sun.y, c_sun.z, 0.0f);
+            if (push_sky) P.c_sky[p] = make_float4(c_sky.x, c_sky.y, c_sky.z, 0.0f);
+            if (has_post) P.c_post[p] = make_float4(c_post.x, c_post.y, c_post.z, 0.0f);
             if (push_sun || push_sky) {
                 P.sh_o[p] = make_float4(sh_o.x, sh_o.y, sh_o.z, 0.0f);
                 P.sh_d[p] = make_float4(sh_d.x, sh_d.y, sh_d.z, 0.0f);
@@ -726,10 +736,14 @@ __global__ void k_finalize(PathArrays P, const uint32_t* q_final, const IterCtr*
         const uint32_t p = q_final[i];
         const float4 ra4 = P.rad[p];
         V3 L = v3(ra4.x, ra4.y, ra4.z);
-        { const float4 a = P.c_sun[p], b = P.c_sky[p], c = P.c_post[p];
+        { const uint32_t pend = __float_as_uint(ra4.w);
+          float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, c = a;
+          if (pend & PEND_SUN) a = P.c_sun[p];
+          if (pend & PEND_SKY) b = P.c_sky[p];
+          if (pend & PEND_POST) c = P.c_post[p];
           L = L + v3(a.x, a.y, a.z); L = L + v3(b.x, b.y, b.z); L = L + v3(c.x, c.y, c.z); }
         const V3 c = clamp_radiance(L);     // pathtracer.rs:325
-        const uint32_t pixel = __float_as_uint(ra4.w);
+        const uint32_t pixel = __float_as_uint(ra4.w) & PIXEL_MASK;
         const size_t o = (size_t)(tg.by_slot ? p : pixel) * 3;
         if (tg.out_rgb) { tg.out_rgb[o] = c.x; tg.out_rgb[o + 1] = c.y; tg.out_rgb[o + 2] = c.z; }
         if (tg.out_albedo) {
@@ -788,7 +802,7 @@ __global__ void k_unshaded(SceneDev S, PathArrays P, uint32_t n, float* out_rgb)
     } else {
         c = sky_sample(S, rd, sc) * 0.5f;
     }
-    const size_t o = (size_t)__float_as_uint(ra4.w) * 3;
+    const size_t o = (size_t)(__float_as_uint(ra4.w) & PIXEL_MASK) * 3;
     out_rgb[o] = c.x; out_rgb[o + 1] = c.y; out_rgb[o + 2] = c.z;
 }
 
@@ -1244,6 +1258,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
                          uint32_t uniform_sample, uint32_t n, uint32_t w, uint32_t h, uint32_t max_bounces, const Target& tg, bool aov,
                          uint32_t batch = 0) {
     if (n == 0) return PTX_OK;
+    if ((uint64_t)w * h > PIXEL_MASK) return fail(ctx, PTX_ERR_UNSUPPORTED, "frames above 2^29 pixels are not supported");
     int32_t st = ensure_capacity(ctx, n);
     if (st != PTX_OK) return st;
     const bool sss = ctx->S.has_sss != 0;
