@@ -69,8 +69,11 @@ constexpr int TRACE_GRID = 256 * 4 * PT_WAVES_PER_SIMD;   // persistent waves, P
 #define PT_SHADE_BLOCK 256
 #endif
 constexpr int SHADE_BLOCK = PT_SHADE_BLOCK;
+// k_shade is a chain of dependent gathers: it runs at the speed its resident waves allow.  168 VGPRs = 3 waves/SIMD
+// without spilling (pending contributions, shadow ray and radiance are stored where they are computed to get there;
+// 4 waves need 88 B of scratch per lane: +0.6 % on the large frames, slower on the small ones).
 #ifndef PT_SHADE_ATTR
-#define PT_SHADE_ATTR
+#define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(3)))
 #endif
 // traversal kernels are compiled for PT_WAVES_PER_SIMD resident waves per SIMD (80 VGPRs at 6)
 #ifndef PT_TRACE_ATTR
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
               if (pend & PEND_POST) c = P.c_post[p];
               L = L + v3(a.x, a.y, a.z); L = L + v3(b.x, b.y, b.z); L = L + v3(c.x, c.y, c.z); }
             V3 c_sun = splat(0.0f), c_sky = splat(0.0f), c_post = splat(0.0f);
-            bool has_post = false;
+            bool has_post = false, l_stored = false;
             V3 sh_o = splat(0.0f), sh_d = splat(0.0f);
             alive = true;
             const V3 sun_dir = v3(S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]);
@@ -379,6 +382,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                         first_hit = false;
                     }
                     L = L + T * mat.emissive;
+                    // L is final for this step: its three words go out now, the pixel/pending word at the end
+                    { float* lr = reinterpret_cast<float*>(&P.rad[p]); lr[0] = L.x; lr[1] = L.y; lr[2] = L.z; }
+                    l_stored = true;
 
                     const bool front_face = dot(rd, hit.geo_normal) < 0.0f;
                     const V3 geo_n = front_face ? hit.geo_normal : -hit.geo_normal;
@@ -439,11 +445,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                         const float alpha = mat.roughness * mat.roughness;
                         const V3 f0 = lerp(splat(0.04f), mat.base_color, mat.metallic);
                         const V3 diffuse_color = mat.base_color * (1.0f - mat.metallic);
-                        V3 tb, bb;
-                        build_basis(nrm, &tb, &bb);
                         const float n_dot_v = f_max(dot(v, nrm), 0.001f);
                         const float spec_prob = compute_spec_prob(n_dot_v, f0, diffuse_color);
                         sh_o = hit_point + geo_n * RAY_EPSILON;
+                        P.sh_o[p] = make_float4(sh_o.x, sh_o.y, sh_o.z, 0.0f);   // stored here: three registers fewer across the sampling code
 
                         // sample_direct_light (pathtracer.rs:372-400): visibility is resolved by k_shadow
                         if (S.sun_enabled) {
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                                 const float mis = mis_weight(S.sun_pdf, brdf_pdf);
                                 c_sun = T * brdf * sun_color * mis;
                                 push_sun = true;
+                                P.c_sun[p] = make_float4(c_sun.x, c_sun.y, c_sun.z, 0.0f);
                             }
                         }
                         // sample_sky_light (pathtracer.rs:402-435)
@@ -475,9 +481,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                                 c_sky = T * brdf * sky_contribution * mis;
                                 sh_d = l;
                                 push_sky = true;
+                                P.c_sky[p] = make_float4(c_sky.x, c_sky.y, c_sky.z, 0.0f);
+                                P.sh_d[p] = make_float4(sh_d.x, sh_d.y, sh_d.z, 0.0f);
                             }
                         }
                         // sample_brdf (pathtracer.rs:437-479)
+                        V3 tb, bb;
+                        build_basis(nrm, &tb, &bb);      // only the BSDF sample needs the frame: built here, not before the NEE code
                         V3 new_dir = splat(0.0f), weight = splat(0.0f);
                         float pdf = 0.0f;
                         bool ok = true;
@@ -520,6 +530,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                                     const float mis = mis_weight(pdf, S.sun_pdf);
                                     c_post = T * sun_color * mis;
                                     has_post = true;
+                                    P.c_post[p] = make_float4(c_post.x, c_post.y, c_post.z, 0.0f);
                                 }
                                 bounce++;
                             }
@@ -634,9 +645,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                     else {
                         const V3 diffuse_brdf = sss_base / PT_PI;
                         sh_o = exit_point + exit_n * RAY_EPSILON;
+                        P.sh_o[p] = make_float4(sh_o.x, sh_o.y, sh_o.z, 0.0f);
                         if (S.sun_enabled) {
                             const float n_dot_l = dot(exit_n, sun_dir);
-                            if (n_dot_l > 0.0f) { c_sun = T * diffuse_brdf * sun_color * n_dot_l; push_sun = true; }
+                            if (n_dot_l > 0.0f) { c_sun = T * diffuse_brdf * sun_color * n_dot_l; push_sun = true; P.c_sun[p] = make_float4(c_sun.x, c_sun.y, c_sun.z, 0.0f); }
                         }
                         {
                             const float u1 = rng.next();
@@ -648,6 +660,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                                 c_sky = T * diffuse_brdf * sky_contribution * n_dot_l;
                                 sh_d = ss.direction;
                                 push_sky = true;
+                                P.c_sky[p] = make_float4(c_sky.x, c_sky.y, c_sky.z, 0.0f);
+                                P.sh_d[p] = make_float4(sh_d.x, sh_d.y, sh_d.z, 0.0f);
                             }
                         }
                         V3 et, eb;
@@ -670,14 +684,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
             flags = (bounce & FL_BOUNCE_MASK) | (last_spec ? FL_SPECULAR : 0u) | (state << FL_STATE_SHIFT) |
                     (first_hit ? FL_FIRST_HIT : 0u) | ((step << FL_STEP_SHIFT) & FL_STEP_MASK);
             const uint32_t pend_next = (push_sun ? PEND_SUN : 0u) | (push_sky ? PEND_SKY : 0u) | (has_post ? PEND_POST : 0u);
-            P.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float((__float_as_uint(ra4.w) & PIXEL_MASK) | pend_next));
-            if (push_sun) P.c_sun[p] = make_float4(c_sun.x, c_sun.y, c_sun.z, 0.0f);
-            if (push_sky) P.c_sky[p] = make_float4(c_sky.x, c_sky.y, c_sky.z, 0.0f);
-            if (has_post) P.c_post[p] = make_float4(c_post.x, c_post.y, c_post.z, 0.0f);
-            if (push_sun || push_sky) {
-                P.sh_o[p] = make_float4(sh_o.x, sh_o.y, sh_o.z, 0.0f);
-                P.sh_d[p] = make_float4(sh_d.x, sh_d.y, sh_d.z, 0.0f);
-            }
+            if (l_stored) reinterpret_cast<uint32_t*>(&P.rad[p])[3] = (__float_as_uint(ra4.w) & PIXEL_MASK) | pend_next;
+            else P.rad[p] = make_float4(L.x, L.y, L.z, __uint_as_float((__float_as_uint(ra4.w) & PIXEL_MASK) | pend_next));
+            // (pending contributions and the shadow rays were stored where they were computed)
             if (alive) {
                 P.ray_o[p] = make_float4(ro.x, ro.y, ro.z, ray_tmax);
                 P.ray_d[p] = make_float4(rd.x, rd.y, rd.z, last_pdf);
