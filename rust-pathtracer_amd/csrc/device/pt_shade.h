@@ -28,9 +28,6 @@ PT_DEV Rng rng_new(uint32_t seed) { Rng r; r.state = (uint64_t)seed; r.next_u32(
 // Texture::sample (texture.rs:64-101): wrap-repeat bilinear over f32 RGB texels.
 PT_DEV V3 texture_sample(const TexRec& t, const float* texels, float uvx, float uvy, uint32_t& lookups) {
     if (t.offset == ~0ull) return v3(t.solid[0], t.solid[1], t.solid[2]);
-#ifdef PT_EXP_NO_TEX
-    return v3(0.5f, 0.5f, 0.5f);
-#endif
     lookups++;
     const float u = rem_euclid1(uvx), v = rem_euclid1(uvy);
     const float px = u * (float)t.width - 0.5f, py = v * (float)t.height - 0.5f;
@@ -139,9 +136,6 @@ PT_DEV SkySample sky_sample_direction(const SceneDev& S, float u1, float u2, Sha
         return r;
     }
     const uint32_t W = S.sky_w, H = S.sky_h;
-#ifdef PT_EXP_NO_CDF
-    r.direction = v3(0.0f, 1.0f, 0.0f); r.radiance = v3(1.0f, 1.0f, 1.0f); r.pdf = 1.0f + u1 + u2; return r;
-#endif
     const uint32_t zero_stride[4] = {0u, 0u, 0u, 0u};
     uint32_t y;
     if (FAST && S.cdf_levels_m) { const uint32_t lo = cdf_count16(S.sky_search, S.cdf_off_m, zero_stride, 0u, S.cdf_levels_m, u1); y = lo == 0u ? 0u : lo - 1u; }
