@@ -10,6 +10,7 @@ Layout
   host.py        ctypes over libpt_host.so   (Scene, SceneBuilder, Camera)
   render.py      ctypes over libmi355_pt.so  (HipRenderLoop: the RenderLoop mirror)
   gltf.py        loader/gltf.rs in Python    (GLB/glTF -> flat scene)
+  exporter.py    PngExporter                 (device tone map + sRGB8, PIL writes the PNG)
   textures.py    Texture::from_file          (sky / texture files: Radiance .hdr, 8/16-bit LDR)
 """
 from . import _abi  # noqa: F401
@@ -18,6 +19,8 @@ from . import host  # noqa: F401
 from . import gltf  # noqa: F401
 from . import render  # noqa: F401
 from . import textures  # noqa: F401
+from . import exporter  # noqa: F401
+from .exporter import PngExporter  # noqa: F401
 from .host import Camera, Scene, SceneBuilder, default_material  # noqa: F401
 from .render import (AdaptiveSamplingConfig, DeviceFramebuffer, HipRenderLoop,  # noqa: F401
                      PathTracer, RenderCoreError, UnshadedRenderer)

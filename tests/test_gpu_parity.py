@@ -270,7 +270,7 @@ def test_gltf_scene_renders_like_the_oracle(pkg, loop, oracle_det, tmp_path):
         assert np.array_equal(bits(osc.render_pass(cam, w, h, s, 8)), bits(loop.render_pass(sc, cam, pkg.PathTracer(8), w, h, s)))
 
 
-def test_device_tonemap_srgb8(pkg, loop, oracle_det, scenes):
+def test_device_tonemap_srgb8(pkg, loop, oracle_det, scenes, tmp_path):
     """ptx_fb_tonemap_srgb8: mean -> ToneMap::apply_with_exposure -> linear_to_srgb_u8 on the device, byte for byte
     the det oracle's (and pow/log2 bit for bit)."""
     sc = scenes("cornell", 1, 1.0)
@@ -287,6 +287,17 @@ def test_device_tonemap_srgb8(pkg, loop, oracle_det, scenes):
         yy = np.full_like(x, np.float32(y))
         assert np.array_equal(bits(loop.debug_math("pow", x, yy)), bits(oracle_det.math("pow", x, yy)))
     assert np.array_equal(bits(loop.debug_math("log2", x[:5002])), bits(oracle_det.math("log2", x[:5002])))
+    # PngExporter (exporter/png.rs): the file holds exactly those bytes; the app exports AgX (app.rs:272)
+    from PIL import Image
+    path = str(tmp_path / "frame.png")
+    pkg.PngExporter.with_tonemap("agx").with_exposure(1.0).export(fb, path)
+    assert np.array_equal(np.asarray(Image.open(path)), oracle_det.tonemap_srgb8(mean, "agx", 1.0))
+    pkg.PngExporter.srgb().export_adaptive(fb, path)
+    assert np.array_equal(np.asarray(Image.open(path)), oracle_det.tonemap_srgb8(mean, "none", 1.0))
+    with pytest.raises(NotImplementedError):
+        pkg.PngExporter.srgb().with_denoiser(object())
+    with pytest.raises(ValueError):
+        pkg.PngExporter("filmic")
 
 
 def test_adaptive_frame_split_over_ranks_is_the_single_gpu_frame(pkg, loop, scenes):
