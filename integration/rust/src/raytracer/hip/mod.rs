@@ -160,6 +160,22 @@ impl HipRenderLoop {
         rendered as usize
     }
 
+    /// Up to `max_passes` adaptive passes between two redraws of the app (app.rs:195-236), traced together on the
+    /// device and replayed per pixel: same accumulators as that many `render_adaptive_pass` calls.
+    /// Returns (passes that rendered something, samples added); (0, 0) means the frame has converged.
+    pub fn render_adaptive_passes<R: Renderer>(&self, camera: &Camera, config: &AdaptiveSamplingConfig, pixels: usize,
+                                               max_passes: u32) -> (u32, usize) {
+        self.set_camera(camera);
+        let cfg = sys::PtxAdaptiveConfig {
+            min_samples: config.min_samples, variance_threshold: config.variance_threshold,
+            max_samples_per_pass: config.max_samples_per_pass.unwrap_or(pixels) as u64,
+        };
+        let (mut passes, mut rendered) = (0u32, 0u64);
+        let st = unsafe { sys::ptx_fb_adaptive_passes(self.ctx, &cfg, R::MAX_BOUNCES, max_passes, &mut passes, &mut rendered) };
+        assert_eq!(st, sys::PTX_OK, "{}", last_error(self.ctx));
+        (passes, rendered as usize)
+    }
+
     /// Pull the device accumulators into the host framebuffer (framebuffer.rs:84-142 fields).
     pub fn read_framebuffer(&self, fb: &mut AdaptiveFramebuffer) {
         let st = unsafe {
