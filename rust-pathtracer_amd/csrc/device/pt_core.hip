@@ -76,6 +76,12 @@ constexpr int SHADE_BLOCK = PT_SHADE_BLOCK;
 #define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(3)))
 #endif
 // traversal kernels are compiled for PT_WAVES_PER_SIMD resident waves per SIMD (80 VGPRs at 6)
+#ifndef PT_PACKET_WAVES
+#define PT_PACKET_WAVES 5
+#endif
+#ifndef PT_PACKET_ATTR
+#define PT_PACKET_ATTR __attribute__((amdgpu_waves_per_eu(PT_PACKET_WAVES)))
+#endif
 #ifndef PT_TRACE_ATTR
 #define PT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_SIMD)))
 #endif
@@ -250,6 +256,26 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S
     trace_queue<false, CNT>(S, st, ctr->w_extend, ctr->n_active, src, sink, lc, nrays, e);
     if (e) atomicOr(err, e);
     if (CNT) flush_lane_cnt(dc, lc, nrays, false);
+}
+
+// Coherent queues (the primary rays of a wavefront batch): the wave's 64 rays walk the tree as one packet.
+__global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_extend_packet(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
+                                                               uint32_t* err) {
+    const StackRef st = make_stack(ovf);
+    uint32_t e = 0;
+    ExtendSrc src{P, q};
+    ExtendSink sink{P};
+    trace_packets(S, st, ctr->w_extend, ctr->n_active, src, sink, e);
+    if (e) atomicOr(err, e);
+}
+__global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_trace_batch_packet(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
+                                                                    uint32_t* work, uint2* ovf, uint32_t* err) {
+    const StackRef st = make_stack(ovf);
+    uint32_t e = 0;
+    BatchSrc src{rays};
+    BatchSink<false> sink{out_hits, nullptr};
+    trace_packets(S, st, work, n, src, sink, e);
+    if (e) atomicOr(err, e);
 }
 
 // ---- shadow: Scene::hit_any for the NEE queue ---------------------------------------
@@ -1040,6 +1066,7 @@ struct PtxContext {
     uint32_t fb_w = 0, fb_h = 0; bool fb_adaptive = false;
     float *fb_sum = nullptr, *fb_sum_sq = nullptr; uint32_t* fb_counts = nullptr;
 
+    bool packet_primary = true, packet_batch = false;   // PTX_PACKET_PRIMARY (0 disables), PTX_PACKET_BATCH (tests: ptx_trace_batch through the packet kernel)
     uint32_t adaptive_batch = 32;   // adaptive passes traced together by ptx_fb_adaptive_passes (PTX_ADAPTIVE_BATCH)
     bool counting = false, profiling = false;
     struct Ev { hipEvent_t a, b; int cls; };
@@ -1278,6 +1305,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
         hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->cam, ctx->P, wl_pixel, wl_sample,
                            per_pixel_counts, uniform_sample, n, w, h, ctx->q[0], ctx->ctrs, aov ? 1u : 0u, (PtxRay*)nullptr, batch);
     }
+    const bool coherent = batch >= 16u || wl_pixel == ctx->wl_pixel;   // a wave's slots are samples of one or two pixels, or a tile of the owned-pixel list
     const int trace_grid = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
     const int shade_grid = (int)std::min<uint64_t>(256 * 8, (n + SHADE_BLOCK - 1) / SHADE_BLOCK);
     for (uint32_t it = 0; it < iter_cap; ++it) {
@@ -1286,7 +1314,10 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
         IterCtr* c = ctx->ctrs + it;
         {
             ScopedEvent ev(ctx, CLS_EXTEND);
-            if (ctx->counting) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+            // primary rays of neighbouring queue entries are coherent (a pixel's samples, or an 8x8 tile): packets
+            if (it == 0 && coherent && ctx->packet_primary && !ctx->counting)
+                hipLaunchKernelGGL(k_extend_packet, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_err);
+            else if (ctx->counting) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
         }
         {
@@ -1353,6 +1384,8 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
         const unsigned long long v = std::strtoull(e, nullptr, 10);
         if (v) c->max_paths_in_flight = v;
     }
+    if (const char* e = std::getenv("PTX_PACKET_PRIMARY")) c->packet_primary = std::strtoul(e, nullptr, 10) != 0;
+    if (const char* e = std::getenv("PTX_PACKET_BATCH")) c->packet_batch = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("PTX_ADAPTIVE_BATCH")) {
         const unsigned long v = std::strtoul(e, nullptr, 10);
         if (v) c->adaptive_batch = (uint32_t)std::min<unsigned long>(v, 256);
@@ -1967,6 +2000,8 @@ int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t
         if (mode == PTX_TRACE_ANY) {
             if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
+        } else if (ctx->packet_batch && !ctx->counting) {
+            hipLaunchKernelGGL(k_trace_batch_packet, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, d_work, ctx->ovf, ctx->d_err);
         } else {
             if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);

@@ -470,4 +470,180 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
     }
 }
 
+// ---- packet traversal (closest hit) ---------------------------------------------------------------
+// For queues whose neighbouring entries are coherent rays (the primary rays of a pixel-major batch: 64 samples of one
+// pixel per wave).  The 64 rays of a wave walk the tree TOGETHER: one stack (every lane keeps its own copy of each
+// entry's word and its own entry distance, +inf where the ray did not hit that child), one record fetch per step
+// from a wave-uniform address, no vote and no idle action.  A ray takes part in an entry exactly when its own
+// traversal would have popped and kept it (`dist < closest_t`), the entries a ray takes part in appear in the order
+// its own stack would have produced (children are pushed in the same slot order, a superset stays LIFO), and all
+// arithmetic is per lane, so hits are bit-identical to trace_queue's; only nodes no ray needs are skipped.
+#ifndef PT_PACKET_CHUNK
+#define PT_PACKET_CHUNK 8
+#endif
+constexpr uint32_t PACKET_CHUNK = PT_PACKET_CHUNK;
+template <class Src, class Sink>
+PT_DEV void trace_packets(const SceneDev& S, const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink,
+                          uint32_t& err) {
+    constexpr uint32_t POS_INF_BITS = 0x7F800000u;
+    constexpr int CAPACITY = LDS_STACK + OVF_STACK;
+    const float tmin = RAY_EPSILON;
+    const uint32_t lane = threadIdx.x & 63u;
+    // PACKET_CHUNK packets per claim: one cursor bumped once per packet would serialise 2 M same-address atomics
+    // (~17 ns each) in a 133 M-ray launch
+    uint32_t base = 0, chunk_left = 0;     // wave-uniform
+    for (;;) {
+        if (chunk_left == 0u) {
+            uint32_t b = 0;
+            if (lane == 0u) b = atomicAdd(work, 64u * PACKET_CHUNK);
+            base = __builtin_amdgcn_readfirstlane(b);
+            chunk_left = PACKET_CHUNK;
+        } else {
+            base += 64u;
+        }
+        chunk_left -= 1u;
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        const bool valid = i < n;
+        uint32_t key = 0;
+        V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(1.0f, 1.0f, 1.0f);
+        float ct = 0.0f;
+        if (valid) { key = src.key(i); src.fetch(key, &o, &d, &ct); }
+        V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);          // Ray::new (ray.rs:13-21)
+        bool exact = ray_needs_exact(o, inv);
+        bool found = false;
+        V3 w_inv = inv;                 // world level, parked while the packet is inside an instance
+        float w_ct = ct;
+        bool w_exact = exact;
+        uint32_t m_tri = PTX_MISS;
+        float m_u = 0.0f, m_v = 0.0f;
+        // wave-uniform state
+        unsigned long long entered = 0ull;
+        uint32_t cur_inst = 0u, tri_base = 0u;
+        bool in_mesh = false;
+        int sp = 0, marker_sp = -1;
+        // Bvh8::traverse_closest: (root, 0.0) is popped first; a lane without a ray never takes part
+        if (S.n_tlas_nodes != 0u) st_write(st, sp++, S.tlas_root_word, valid ? 0u : POS_INF_BITS);
+        while (sp > 0) {
+            --sp;
+            if (in_mesh && sp == marker_sp) {
+                // ---- tail of Instance::hit (accel/mod.rs:128-137) for the lanes that entered
+                const bool was = ((entered >> lane) & 1ull) != 0ull;
+                if (was) {
+                    V3 wo, wd;
+                    float unused_tmax;
+                    src.fetch(key, &wo, &wd, &unused_tmax);
+                    if (m_tri != PTX_MISS) {
+                        const float4* p = reinterpret_cast<const float4*>(&S.inst[cur_inst]);
+                        const float4 ma = p[5], mb = p[6], mc = p[7];
+                        const V3 local_hit_point = o + ct * d;
+                        const V3 world_hit_point = xf_point(ma, mb, mc, local_hit_point);
+                        const float t_world = dot(world_hit_point - wo, wd) / dot(wd, wd);
+                        if (t_world < w_ct) {                       // traverse_closest accept (accel/bvh.rs:353-357)
+                            w_ct = t_world;
+                            sink.hit(key, cur_inst, m_tri, t_world, m_u, m_v);
+                            found = true;
+                        }
+                    }
+                    o = wo; d = wd; inv = w_inv; ct = w_ct; exact = w_exact;
+                    m_tri = PTX_MISS;
+                }
+                in_mesh = false;
+                entered = 0ull;
+                continue;
+            }
+            const uint2 e = st_read(st, sp);
+            const uint32_t word = __builtin_amdgcn_readfirstlane(e.x);
+            const bool act = !(__uint_as_float(e.y) >= ct);          // the pop-time cull (accel/bvh.rs:327-329), per ray
+            if (__ballot(act) == 0ull) continue;
+            if (sp + 6 > CAPACITY) { err = 1u; found = false; sp = 0; break; }
+            if (word & LEAF_FLAG) {
+                const uint32_t start = word & PRIM_START_MASK;
+                const uint32_t count = ((word >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
+                if (in_mesh) {
+                    // the leaf's triangles in order (triangle_mesh.rs:64-100 under accel/bvh.rs:348-357)
+                    for (uint32_t j = 0; j < count; ++j) {
+                        const float4* p = reinterpret_cast<const float4*>(&S.tris[tri_base + start + j]);
+                        const float4 ta = p[0], tb = p[1], tc = p[2];
+                        const V3 v0 = v3(ta.x, ta.y, ta.z), edge1 = v3(ta.w, tb.x, tb.y), edge2 = v3(tb.z, tb.w, tc.x);
+                        const V3 h = cross(d, edge2);
+                        const float a = dot(edge1, h);
+                        const float f = 1.0f / a;
+                        const V3 sv = o - v0;
+                        const float u = f * dot(sv, h);
+                        const V3 q = cross(sv, edge1);
+                        const float v = f * dot(d, q);
+                        const float t = f * dot(edge2, q);
+                        const bool hit = !(fabsf(a) < 1e-8f) && (u >= 0.0f && u <= 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
+                                         (t >= tmin && t <= PT_INF);
+                        if (act && hit && t < ct) { ct = t; m_tri = __float_as_uint(tc.y); m_u = u; m_v = v; }
+                    }
+                } else {
+                    // TLAS leaf: this primitive now, the rest afterwards and uncullable (the reference's inner loop)
+                    if (count > 1u) st_write(st, sp++, LEAF_FLAG | ((count - 2u) << PRIM_COUNT_SHIFT) | (start + 1u), act ? NEG_INF_BITS : POS_INF_BITS);
+                    const float4* p = reinterpret_cast<const float4*>(&S.inst_tlas[start]);
+                    const float4 ia = p[0], ib = p[1], ic = p[2], b0 = p[3], b1 = p[4];
+                    const uint32_t inst_idx = S.tlas_prims[start];
+                    const V3 lo = xf_point(ia, ib, ic, o);
+                    const V3 ld = xf_vector(ia, ib, ic, d);
+                    const V3 linv = v3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+                    const bool lexact = ray_needs_exact(lo, linv);
+                    float tb_enter;
+                    bool bhit;
+                    if (__ballot(act && lexact) != 0ull) bhit = box_test<true>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
+                    else bhit = box_test<false>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
+                    const bool enter = act && bhit && !(tb_enter >= PT_INF);
+                    const unsigned long long em = __ballot(enter);
+                    if (em == 0ull) continue;
+                    // park the world level under a marker entry and descend into the mesh BVH
+                    // (TriangleMesh::hit: closest_t = local t_max = +inf; root popped with dist 0)
+                    if (enter) { w_inv = inv; w_ct = ct; w_exact = exact; }
+                    entered = em;
+                    cur_inst = inst_idx;
+                    tri_base = __float_as_uint(b1.w);
+                    marker_sp = sp;
+                    st_write(st, sp++, 0u, 0u);
+                    st_write(st, sp++, __float_as_uint(b1.z), enter ? 0u : POS_INF_BITS);
+                    if (enter) { o = lo; d = ld; inv = linv; exact = lexact; ct = PT_INF; m_tri = PTX_MISS; }
+                    in_mesh = true;
+                }
+            } else {
+                // ---- node.intersect for every ray that takes part + the slot loop's pushes
+                const uint32_t nchild = ((word >> NODE_NCHILD_SHIFT) & 3u) + 1u;
+                const float4* p = reinterpret_cast<const float4*>(&S.nodes[word & NODE_INDEX_MASK]);
+                const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3], c0 = p[4], c1 = p[5];
+                float4 d0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d1 = d0;
+                if (nchild > 3u) { d0 = p[6]; d1 = p[7]; }
+                float te0, te1, te2, te3 = 0.0f;
+                bool h0, h1, h2, h3 = false;
+                if (__ballot(act && exact) != 0ull) {
+                    h0 = box_test<true>(a0, a1, o, inv, tmin, ct, &te0);
+                    h1 = box_test<true>(b0, b1, o, inv, tmin, ct, &te1);
+                    h2 = box_test<true>(c0, c1, o, inv, tmin, ct, &te2);
+                    if (nchild > 3u) h3 = box_test<true>(d0, d1, o, inv, tmin, ct, &te3);
+                } else {
+                    h0 = box_test<false>(a0, a1, o, inv, tmin, ct, &te0);
+                    h1 = box_test<false>(b0, b1, o, inv, tmin, ct, &te1);
+                    h2 = box_test<false>(c0, c1, o, inv, tmin, ct, &te2);
+                    if (nchild > 3u) h3 = box_test<false>(d0, d1, o, inv, tmin, ct, &te3);
+                }
+                h0 = h0 && act; h1 = h1 && act && nchild > 1u; h2 = h2 && act && nchild > 2u; h3 = h3 && act;
+                const uint32_t w0 = __float_as_uint(a1.z), w1 = __float_as_uint(b1.z), w2 = __float_as_uint(c1.z), w3 = __float_as_uint(d1.z);
+                const bool any0 = __ballot(h0) != 0ull, any1 = __ballot(h1) != 0ull, any2 = __ballot(h2) != 0ull, any3 = __ballot(h3) != 0ull;
+                // internal children in ascending slot order (accel/bvh.rs:360-363), leaf children on top in descending
+                // order so that they pop first and in slot order
+                if (any0 && !(w0 & LEAF_FLAG)) st_write(st, sp++, w0, h0 ? __float_as_uint(te0) : POS_INF_BITS);
+                if (any1 && !(w1 & LEAF_FLAG)) st_write(st, sp++, w1, h1 ? __float_as_uint(te1) : POS_INF_BITS);
+                if (any2 && !(w2 & LEAF_FLAG)) st_write(st, sp++, w2, h2 ? __float_as_uint(te2) : POS_INF_BITS);
+                if (any3 && !(w3 & LEAF_FLAG)) st_write(st, sp++, w3, h3 ? __float_as_uint(te3) : POS_INF_BITS);
+                if (any3 && (w3 & LEAF_FLAG)) st_write(st, sp++, w3, h3 ? __float_as_uint(te3) : POS_INF_BITS);
+                if (any2 && (w2 & LEAF_FLAG)) st_write(st, sp++, w2, h2 ? __float_as_uint(te2) : POS_INF_BITS);
+                if (any1 && (w1 & LEAF_FLAG)) st_write(st, sp++, w1, h1 ? __float_as_uint(te1) : POS_INF_BITS);
+                if (any0 && (w0 & LEAF_FLAG)) st_write(st, sp++, w0, h0 ? __float_as_uint(te0) : POS_INF_BITS);
+            }
+        }
+        if (valid) sink.done(key, found);
+    }
+}
+
 }  // namespace ptd

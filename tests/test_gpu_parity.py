@@ -84,6 +84,25 @@ def test_hit_records_bit_exact(pkg, loop, oracle_det, scenes, name, flags, detai
     assert not oracle_det.stack_overflowed()
 
 
+@pytest.mark.parametrize("name,flags,detail,w,h,bounces", SCENES)
+def test_packet_traversal_bit_exact(pkg, oracle_det, scenes, monkeypatch, name, flags, detail, w, h, bounces):
+    """trace_packets (the wave's 64 rays walk the tree together; used for the primary rays of a frame) must return the
+    per-ray traversal's hit records bit for bit — on coherent primaries, on incoherent bounce rays where the packet is
+    the union of 64 unrelated walks, and on finite-t_max segments."""
+    abi = pkg._abi
+    monkeypatch.setenv("PTX_PACKET_BATCH", "1")
+    lp = pkg.HipRenderLoop(0)                      # reads PTX_PACKET_BATCH at creation
+    sc = scenes(name, flags, detail)
+    cam = sc.default_camera(w / h)
+    osc = oracle_det.scene(sc)
+    prim = osc.primary_rays(cam, w, h, 3)
+    hc = osc.trace_closest(prim)
+    for rays in (prim, secondary_rays(abi, osc, prim, hc, 7), prim[: 64 * 3 + 5]):     # the last one: a ragged final packet
+        c = osc.trace_closest(rays)
+        g = lp.trace_closest(sc, rays)
+        assert np.array_equal(c.view(np.uint8), g.view(np.uint8))
+
+
 def test_axis_aligned_rays_nan_slabs(pkg, loop, oracle_det, scenes):
     """Rays with zero direction components whose origin lies on slab planes of axis-aligned walls:
     0 * inf = NaN inside the node test; the x86 min_ps/max_ps NaN rules decide the outcome."""
