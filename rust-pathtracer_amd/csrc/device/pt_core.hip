@@ -64,6 +64,10 @@ constexpr uint32_t MAX_ITERS = 4096;
 // the light is below the surface)
 constexpr uint32_t PEND_SUN = 1u << 29, PEND_SKY = 1u << 30, PEND_POST = 1u << 31, PIXEL_MASK = (1u << 29) - 1u;
 
+#ifndef PT_PACKET_GRID_WAVES
+#define PT_PACKET_GRID_WAVES PT_WAVES_PER_SIMD
+#endif
+constexpr int PACKET_GRID = 256 * 4 * PT_PACKET_GRID_WAVES;   // the packet kernel needs fewer registers: more resident waves
 constexpr int TRACE_GRID = 256 * 4 * PT_WAVES_PER_SIMD;   // persistent waves, PT_WAVES_PER_SIMD per SIMD: the VGPR and LDS budget
 #ifndef PT_SHADE_BLOCK
 #define PT_SHADE_BLOCK 256
@@ -260,12 +264,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S
 
 // Coherent queues (the primary rays of a wavefront batch): the wave's 64 rays walk the tree as one packet.
 __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_extend_packet(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
-                                                               uint32_t* err) {
+                                                               uint32_t* err, const NodeRec* __restrict__ g_nodes, const TriRec* __restrict__ g_tris,
+                                                               const InstRec* __restrict__ g_inst_tlas, const InstRec* __restrict__ g_inst,
+                                                               const uint32_t* __restrict__ g_tlas_prims) {
     const StackRef st = make_stack(ovf);
     uint32_t e = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
-    trace_packets(S, st, ctr->w_extend, ctr->n_active, src, sink, e);
+    trace_packets(S, g_nodes, g_tris, g_inst_tlas, g_inst, g_tlas_prims, st, ctr->w_extend, ctr->n_active, src, sink, e);
     if (e) atomicOr(err, e);
 }
 __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_trace_batch_packet(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_trace_batch_pack
     uint32_t e = 0;
     BatchSrc src{rays};
     BatchSink<false> sink{out_hits, nullptr};
-    trace_packets(S, st, work, n, src, sink, e);
+    trace_packets(S, S.nodes, S.tris, S.inst_tlas, S.inst, S.tlas_prims, st, work, n, src, sink, e);
     if (e) atomicOr(err, e);
 }
 
@@ -1316,7 +1322,8 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
             ScopedEvent ev(ctx, CLS_EXTEND);
             // primary rays of neighbouring queue entries are coherent (a pixel's samples, or an 8x8 tile): packets
             if (it == 0 && coherent && ctx->packet_primary && !ctx->counting)
-                hipLaunchKernelGGL(k_extend_packet, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_err);
+                hipLaunchKernelGGL(k_extend_packet, dim3((int)std::min<uint64_t>(PACKET_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK)), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_err,
+                                   ctx->S.nodes, ctx->S.tris, ctx->S.inst_tlas, ctx->S.inst, ctx->S.tlas_prims);
             else if (ctx->counting) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
         }
@@ -1392,7 +1399,7 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
     }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * MAX_ITERS));
-    HIPCHK(hipMalloc((void**)&c->ovf, sizeof(uint2) * (size_t)TRACE_GRID * TRACE_BLOCK * OVF_STACK));
+    HIPCHK(hipMalloc((void**)&c->ovf, sizeof(uint2) * (size_t)std::max(TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
     HIPCHK(hipMalloc((void**)&c->d_err, 4));
     HIPCHK(hipMemset(c->d_err, 0, 4));
     HIPCHK(hipMalloc((void**)&c->d_counters, sizeof(DevCounters)));

@@ -483,8 +483,9 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
 #endif
 constexpr uint32_t PACKET_CHUNK = PT_PACKET_CHUNK;
 template <class Src, class Sink>
-PT_DEV void trace_packets(const SceneDev& S, const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink,
-                          uint32_t& err) {
+PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes, const TriRec* __restrict__ g_tris,
+                          const InstRec* __restrict__ g_inst_tlas, const InstRec* __restrict__ g_inst, const uint32_t* __restrict__ g_tlas_prims,
+                          const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink, uint32_t& err) {
     constexpr uint32_t POS_INF_BITS = 0x7F800000u;
     constexpr int CAPACITY = LDS_STACK + OVF_STACK;
     const float tmin = RAY_EPSILON;
@@ -534,7 +535,7 @@ PT_DEV void trace_packets(const SceneDev& S, const StackRef& st, uint32_t* work,
                     float unused_tmax;
                     src.fetch(key, &wo, &wd, &unused_tmax);
                     if (m_tri != PTX_MISS) {
-                        const float4* p = reinterpret_cast<const float4*>(&S.inst[cur_inst]);
+                        const float4* p = reinterpret_cast<const float4*>(&g_inst[cur_inst]);
                         const float4 ma = p[5], mb = p[6], mc = p[7];
                         const V3 local_hit_point = o + ct * d;
                         const V3 world_hit_point = xf_point(ma, mb, mc, local_hit_point);
@@ -563,7 +564,7 @@ PT_DEV void trace_packets(const SceneDev& S, const StackRef& st, uint32_t* work,
                 if (in_mesh) {
                     // the leaf's triangles in order (triangle_mesh.rs:64-100 under accel/bvh.rs:348-357)
                     for (uint32_t j = 0; j < count; ++j) {
-                        const float4* p = reinterpret_cast<const float4*>(&S.tris[tri_base + start + j]);
+                        const float4* p = reinterpret_cast<const float4*>(&g_tris[tri_base + start + j]);
                         const float4 ta = p[0], tb = p[1], tc = p[2];
                         const V3 v0 = v3(ta.x, ta.y, ta.z), edge1 = v3(ta.w, tb.x, tb.y), edge2 = v3(tb.z, tb.w, tc.x);
                         const V3 h = cross(d, edge2);
@@ -581,9 +582,9 @@ PT_DEV void trace_packets(const SceneDev& S, const StackRef& st, uint32_t* work,
                 } else {
                     // TLAS leaf: this primitive now, the rest afterwards and uncullable (the reference's inner loop)
                     if (count > 1u) st_write(st, sp++, LEAF_FLAG | ((count - 2u) << PRIM_COUNT_SHIFT) | (start + 1u), act ? NEG_INF_BITS : POS_INF_BITS);
-                    const float4* p = reinterpret_cast<const float4*>(&S.inst_tlas[start]);
+                    const float4* p = reinterpret_cast<const float4*>(&g_inst_tlas[start]);
                     const float4 ia = p[0], ib = p[1], ic = p[2], b0 = p[3], b1 = p[4];
-                    const uint32_t inst_idx = S.tlas_prims[start];
+                    const uint32_t inst_idx = g_tlas_prims[start];
                     const V3 lo = xf_point(ia, ib, ic, o);
                     const V3 ld = xf_vector(ia, ib, ic, d);
                     const V3 linv = v3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
@@ -610,7 +611,7 @@ PT_DEV void trace_packets(const SceneDev& S, const StackRef& st, uint32_t* work,
             } else {
                 // ---- node.intersect for every ray that takes part + the slot loop's pushes
                 const uint32_t nchild = ((word >> NODE_NCHILD_SHIFT) & 3u) + 1u;
-                const float4* p = reinterpret_cast<const float4*>(&S.nodes[word & NODE_INDEX_MASK]);
+                const float4* p = reinterpret_cast<const float4*>(&g_nodes[word & NODE_INDEX_MASK]);
                 const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3], c0 = p[4], c1 = p[5];
                 float4 d0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d1 = d0;
                 if (nchild > 3u) { d0 = p[6]; d1 = p[7]; }
