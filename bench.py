@@ -112,9 +112,9 @@ def main():
         d_sq = torch.empty(h * w * 3, dtype=torch.float32, device="cuda")
         d_cnt = torch.empty(h * w, dtype=torch.int32, device="cuda")
 
-    def frame():
+    def frame(r=None):
         fb.reset()
-        fb.render_passes(scene, cam, renderer, 0, spp)
+        fb.render_passes(scene, cam, r or renderer, 0, spp)
         if world > 1:
             fb.export_dev(d_sum.data_ptr(), d_sq.data_ptr(), d_cnt.data_ptr())
             loop.sync()                       # library stream -> visible to torch's stream
@@ -139,13 +139,22 @@ def main():
     frame()
     fence()
     cnt = loop.counters()
+    # the same frame cut after its primary rays (PathTracer<1>): the closest-hit events of the first extend launch,
+    # which the timed frames trace with the packet kernel; the per-ray kernel's bytes are the rest
+    loop.reset_counters()
+    frame(pkg.PathTracer(1))
+    fence()
+    cnt_primary = loop.counters()
     loop.set_counting(False)
-    note("counted frame done")
+    note("counted frames done")
     if world > 1:
         keys = sorted(cnt)
         t = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t)
         cnt = {k: int(v) for k, v in zip(keys, t.tolist())}
+        t = torch.tensor([cnt_primary[k] for k in keys], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        cnt_primary = {k: int(v) for k, v in zip(keys, t.tolist())}
         note("counters reduced")
 
     for _ in range(args.warmup):
@@ -177,13 +186,23 @@ def main():
     # roofline of the dominant kernel (k_extend), rank 0's launches, HIP events on the library stream
     ext_launches = max(1, tim["extend_launches"])
     ext_ms = tim["extend_ms"] / ext_launches
+    # k_extend's launches are every iteration but those traced as packets (the primary rays, k_extend_packet):
+    # its bytes are the frame's closest-hit bytes minus the primary launch's
+    pk_launches = int(tim["packet_launches"])
+    per_ray_bytes = extend_bytes(cnt) - (extend_bytes(cnt_primary) if pk_launches else 0)
     # rank 0 traced 1/world of the frame's extend work (tile interleave): per-launch bytes on this rank
-    ext_bytes_launch = extend_bytes(cnt) / world * args.steps / ext_launches
+    ext_bytes_launch = per_ray_bytes / world * args.steps / ext_launches
     achieved = ext_bytes_launch / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "algorithmic_bytes_per_launch": round(ext_bytes_launch), "avg_launch_ms": round(ext_ms, 4),
                 "launches": int(ext_launches)}
+    if pk_launches:
+        pk_ms = tim["packet_ms"] / pk_launches
+        pk_bytes = extend_bytes(cnt_primary) / world * args.steps / pk_launches
+        roofline["primary_packets"] = {"kernel": "k_extend_packet", "launches": pk_launches, "avg_launch_ms": round(pk_ms, 4),
+                                       "algorithmic_bytes_per_launch": round(pk_bytes),
+                                       "achieved": round(pk_bytes / (pk_ms * 1e-3) / 1e9, 2), "unit": "GB/s"}
     traffic_file = os.path.join(ROOT, "profiles", "extend_traffic.json")
     if os.path.exists(traffic_file):
         try:
@@ -206,7 +225,7 @@ def main():
         "algorithmic_bytes_per_frame": abytes_frame,
         "frame_hbm_frac": round(abytes_frame / sec_per_frame / 1e9 / HBM_PEAK_GBS, 5),
         "kernel_ms_per_frame": {k: round(tim[k] / args.steps, 3) for k in
-                                ("raygen_ms", "extend_ms", "shade_ms", "shadow_ms", "accumulate_ms")},
+                                ("raygen_ms", "packet_ms", "extend_ms", "shade_ms", "shadow_ms", "accumulate_ms")},
         "scene_build_s": round(build_s, 2),
         "roofline": roofline,
     }

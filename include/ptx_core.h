@@ -238,6 +238,10 @@ typedef struct PtxAdaptiveConfig {
 typedef struct PtxTimings {
     double raygen_ms, extend_ms, shade_ms, shadow_ms, accumulate_ms, other_ms;
     uint64_t extend_launches, shade_launches, shadow_launches;
+    /* closest-hit launches traced as packets (the primary rays of a frame): their own kernel, so their own line;
+     * extend_ms / extend_launches are the per-ray kernel's alone */
+    double packet_ms;
+    uint64_t packet_launches;
 } PtxTimings;
 
 typedef struct PtxContext PtxContext;

@@ -156,6 +156,7 @@ class PtxTimings(C.Structure):
         ("raygen_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
         ("shadow_ms", C.c_double), ("accumulate_ms", C.c_double), ("other_ms", C.c_double),
         ("extend_launches", c_u64), ("shade_launches", c_u64), ("shadow_launches", c_u64),
+        ("packet_ms", C.c_double), ("packet_launches", c_u64),
     ]
 
 

@@ -1252,7 +1252,7 @@ static int32_t ensure_worklist(PtxContext* ctx, uint32_t w, uint32_t h) {
     return PTX_OK;
 }
 
-enum { CLS_RAYGEN = 0, CLS_EXTEND, CLS_SHADE, CLS_SHADOW, CLS_ACCUM, CLS_OTHER };
+enum { CLS_RAYGEN = 0, CLS_EXTEND, CLS_SHADE, CLS_SHADOW, CLS_ACCUM, CLS_OTHER, CLS_PACKET };
 struct ScopedEvent {
     PtxContext* ctx; int idx = -1;
     ScopedEvent(PtxContext* c, int cls) : ctx(c) {
@@ -1273,6 +1273,7 @@ static void drain_events(PtxContext* ctx) {
             switch (e.cls) {
                 case CLS_RAYGEN: ctx->timings.raygen_ms += ms; break;
                 case CLS_EXTEND: ctx->timings.extend_ms += ms; ctx->timings.extend_launches++; break;
+                case CLS_PACKET: ctx->timings.packet_ms += ms; ctx->timings.packet_launches++; break;
                 case CLS_SHADE: ctx->timings.shade_ms += ms; ctx->timings.shade_launches++; break;
                 case CLS_SHADOW: ctx->timings.shadow_ms += ms; ctx->timings.shadow_launches++; break;
                 case CLS_ACCUM: ctx->timings.accumulate_ms += ms; break;
@@ -1319,9 +1320,10 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
         uint32_t* qb = ctx->q[(it + 1) & 1];
         IterCtr* c = ctx->ctrs + it;
         {
-            ScopedEvent ev(ctx, CLS_EXTEND);
             // primary rays of neighbouring queue entries are coherent (a pixel's samples, or an 8x8 tile): packets
-            if (it == 0 && coherent && ctx->packet_primary && !ctx->counting)
+            const bool packets = it == 0 && coherent && ctx->packet_primary && !ctx->counting;
+            ScopedEvent ev(ctx, packets ? CLS_PACKET : CLS_EXTEND);
+            if (packets)
                 hipLaunchKernelGGL(k_extend_packet, dim3((int)std::min<uint64_t>(PACKET_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK)), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_err,
                                    ctx->S.nodes, ctx->S.tris, ctx->S.inst_tlas, ctx->S.inst, ctx->S.tlas_prims);
             else if (ctx->counting) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
