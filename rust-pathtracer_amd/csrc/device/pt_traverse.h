@@ -478,6 +478,35 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
 // traversal would have popped and kept it (`dist < closest_t`), the entries a ray takes part in appear in the order
 // its own stack would have produced (children are pushed in the same slot order, a superset stays LIFO), and all
 // arithmetic is per lane, so hits are bit-identical to trace_queue's; only nodes no ray needs are skipped.
+// The packet stack: one entry = a wave-uniform word + one entry distance per lane.  23 entries live in LDS (5.9 KiB
+// per wave, the per-ray kernels' budget, but twice their depth because a lane stores 4 bytes per entry, not 8);
+// deeper entries go to the per-lane HBM strips.
+#ifndef PT_PACKET_LDS
+#define PT_PACKET_LDS 23
+#endif
+constexpr int PACKET_LDS = PT_PACKET_LDS;
+static __shared__ uint32_t s_pdist[PACKET_LDS * TRACE_BLOCK];
+static __shared__ uint32_t s_pword[PACKET_LDS];
+PT_DEV void pk_write(const StackRef& s, int i, uint32_t word, uint32_t dist_bits) {      // i and word are wave-uniform
+    if (i < PACKET_LDS) {
+        s_pdist[i * TRACE_BLOCK + (int)threadIdx.x] = dist_bits;
+        s_pword[i] = word;
+    } else {
+        s.ovf[(size_t)(i - PACKET_LDS) * s.ovf_stride] = make_uint2(word, dist_bits);
+    }
+}
+PT_DEV uint2 pk_read(const StackRef& s, int i) {
+    uint2 v;
+    if (i < PACKET_LDS) {
+        v.x = s_pword[i];
+        v.y = s_pdist[i * TRACE_BLOCK + (int)threadIdx.x];
+        asm volatile("" : "+v"(v.x), "+v"(v.y));
+    } else {
+        v = s.ovf[(size_t)(i - PACKET_LDS) * s.ovf_stride];
+    }
+    return v;
+}
+
 #ifndef PT_PACKET_CHUNK
 #define PT_PACKET_CHUNK 8
 #endif
@@ -487,7 +516,7 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                           const InstRec* __restrict__ g_inst_tlas, const InstRec* __restrict__ g_inst, const uint32_t* __restrict__ g_tlas_prims,
                           const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink, uint32_t& err) {
     constexpr uint32_t POS_INF_BITS = 0x7F800000u;
-    constexpr int CAPACITY = LDS_STACK + OVF_STACK;
+    constexpr int CAPACITY = PACKET_LDS + OVF_STACK;
     const float tmin = RAY_EPSILON;
     const uint32_t lane = threadIdx.x & 63u;
     // PACKET_CHUNK packets per claim: one cursor bumped once per packet would serialise 2 M same-address atomics
@@ -524,7 +553,7 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
         bool in_mesh = false;
         int sp = 0, marker_sp = -1;
         // Bvh8::traverse_closest: (root, 0.0) is popped first; a lane without a ray never takes part
-        if (S.n_tlas_nodes != 0u) st_write(st, sp++, S.tlas_root_word, valid ? 0u : POS_INF_BITS);
+        if (S.n_tlas_nodes != 0u) pk_write(st, sp++, S.tlas_root_word, valid ? 0u : POS_INF_BITS);
         while (sp > 0) {
             --sp;
             if (in_mesh && sp == marker_sp) {
@@ -553,7 +582,7 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                 entered = 0ull;
                 continue;
             }
-            const uint2 e = st_read(st, sp);
+            const uint2 e = pk_read(st, sp);
             const uint32_t word = __builtin_amdgcn_readfirstlane(e.x);
             const bool act = !(__uint_as_float(e.y) >= ct);          // the pop-time cull (accel/bvh.rs:327-329), per ray
             if (__ballot(act) == 0ull) continue;
@@ -581,7 +610,7 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                     }
                 } else {
                     // TLAS leaf: this primitive now, the rest afterwards and uncullable (the reference's inner loop)
-                    if (count > 1u) st_write(st, sp++, LEAF_FLAG | ((count - 2u) << PRIM_COUNT_SHIFT) | (start + 1u), act ? NEG_INF_BITS : POS_INF_BITS);
+                    if (count > 1u) pk_write(st, sp++, LEAF_FLAG | ((count - 2u) << PRIM_COUNT_SHIFT) | (start + 1u), act ? NEG_INF_BITS : POS_INF_BITS);
                     const float4* p = reinterpret_cast<const float4*>(&g_inst_tlas[start]);
                     const float4 ia = p[0], ib = p[1], ic = p[2], b0 = p[3], b1 = p[4];
                     const uint32_t inst_idx = g_tlas_prims[start];
@@ -603,8 +632,8 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                     cur_inst = inst_idx;
                     tri_base = __float_as_uint(b1.w);
                     marker_sp = sp;
-                    st_write(st, sp++, 0u, 0u);
-                    st_write(st, sp++, __float_as_uint(b1.z), enter ? 0u : POS_INF_BITS);
+                    pk_write(st, sp++, 0u, 0u);
+                    pk_write(st, sp++, __float_as_uint(b1.z), enter ? 0u : POS_INF_BITS);
                     if (enter) { o = lo; d = ld; inv = linv; exact = lexact; ct = PT_INF; m_tri = PTX_MISS; }
                     in_mesh = true;
                 }
@@ -633,14 +662,14 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                 const bool any0 = __ballot(h0) != 0ull, any1 = __ballot(h1) != 0ull, any2 = __ballot(h2) != 0ull, any3 = __ballot(h3) != 0ull;
                 // internal children in ascending slot order (accel/bvh.rs:360-363), leaf children on top in descending
                 // order so that they pop first and in slot order
-                if (any0 && !(w0 & LEAF_FLAG)) st_write(st, sp++, w0, h0 ? __float_as_uint(te0) : POS_INF_BITS);
-                if (any1 && !(w1 & LEAF_FLAG)) st_write(st, sp++, w1, h1 ? __float_as_uint(te1) : POS_INF_BITS);
-                if (any2 && !(w2 & LEAF_FLAG)) st_write(st, sp++, w2, h2 ? __float_as_uint(te2) : POS_INF_BITS);
-                if (any3 && !(w3 & LEAF_FLAG)) st_write(st, sp++, w3, h3 ? __float_as_uint(te3) : POS_INF_BITS);
-                if (any3 && (w3 & LEAF_FLAG)) st_write(st, sp++, w3, h3 ? __float_as_uint(te3) : POS_INF_BITS);
-                if (any2 && (w2 & LEAF_FLAG)) st_write(st, sp++, w2, h2 ? __float_as_uint(te2) : POS_INF_BITS);
-                if (any1 && (w1 & LEAF_FLAG)) st_write(st, sp++, w1, h1 ? __float_as_uint(te1) : POS_INF_BITS);
-                if (any0 && (w0 & LEAF_FLAG)) st_write(st, sp++, w0, h0 ? __float_as_uint(te0) : POS_INF_BITS);
+                if (any0 && !(w0 & LEAF_FLAG)) pk_write(st, sp++, w0, h0 ? __float_as_uint(te0) : POS_INF_BITS);
+                if (any1 && !(w1 & LEAF_FLAG)) pk_write(st, sp++, w1, h1 ? __float_as_uint(te1) : POS_INF_BITS);
+                if (any2 && !(w2 & LEAF_FLAG)) pk_write(st, sp++, w2, h2 ? __float_as_uint(te2) : POS_INF_BITS);
+                if (any3 && !(w3 & LEAF_FLAG)) pk_write(st, sp++, w3, h3 ? __float_as_uint(te3) : POS_INF_BITS);
+                if (any3 && (w3 & LEAF_FLAG)) pk_write(st, sp++, w3, h3 ? __float_as_uint(te3) : POS_INF_BITS);
+                if (any2 && (w2 & LEAF_FLAG)) pk_write(st, sp++, w2, h2 ? __float_as_uint(te2) : POS_INF_BITS);
+                if (any1 && (w1 & LEAF_FLAG)) pk_write(st, sp++, w1, h1 ? __float_as_uint(te1) : POS_INF_BITS);
+                if (any0 && (w0 & LEAF_FLAG)) pk_write(st, sp++, w0, h0 ? __float_as_uint(te0) : POS_INF_BITS);
             }
         }
         if (valid) sink.done(key, found);
