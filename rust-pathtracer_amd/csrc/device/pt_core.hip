@@ -271,16 +271,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_extend_packet(Sc
     uint32_t e = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
-    trace_packets(S, g_nodes, g_tris, g_inst_tlas, g_inst, g_tlas_prims, st, ctr->w_extend, ctr->n_active, src, sink, e);
+    trace_packets<false>(S, g_nodes, g_tris, g_inst_tlas, g_inst, g_tlas_prims, st, ctr->w_extend, ctr->n_active, src, sink, e);
     if (e) atomicOr(err, e);
 }
+template <bool ANY>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_trace_batch_packet(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
-                                                                    uint32_t* work, uint2* ovf, uint32_t* err) {
+                                                                    uint8_t* out_any, uint32_t* work, uint2* ovf, uint32_t* err) {
     const StackRef st = make_stack(ovf);
     uint32_t e = 0;
     BatchSrc src{rays};
-    BatchSink<false> sink{out_hits, nullptr};
-    trace_packets(S, S.nodes, S.tris, S.inst_tlas, S.inst, S.tlas_prims, st, work, n, src, sink, e);
+    BatchSink<ANY> sink{out_hits, out_any};
+    trace_packets<ANY>(S, S.nodes, S.tris, S.inst_tlas, S.inst, S.tlas_prims, st, work, n, src, sink, e);
     if (e) atomicOr(err, e);
 }
 
@@ -319,6 +320,20 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_shadow(SceneDev S
     trace_queue<true, CNT>(S, st, ctr->w_shadow, ctr->n_shadow, src, sink, lc, nrays, e);
     if (e) atomicOr(err, e);
     if (CNT) flush_lane_cnt(dc, lc, nrays, true);
+}
+
+// The shadow rays of the primary hits: a pixel's 64 samples start within its footprint and aim at the sun or at the
+// bright part of the sky, so they too walk the tree as packets.
+__global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_shadow_packet(SceneDev S, PathArrays P, const uint32_t* qs, IterCtr* ctr, uint2* ovf,
+                                                               uint32_t* err, const NodeRec* __restrict__ g_nodes, const TriRec* __restrict__ g_tris,
+                                                               const InstRec* __restrict__ g_inst_tlas, const InstRec* __restrict__ g_inst,
+                                                               const uint32_t* __restrict__ g_tlas_prims) {
+    const StackRef st = make_stack(ovf);
+    uint32_t e = 0;
+    ShadowSrc src{S, P, qs};
+    ShadowSink sink{P};
+    trace_packets<true>(S, g_nodes, g_tris, g_inst_tlas, g_inst, g_tlas_prims, st, ctr->w_shadow, ctr->n_shadow, src, sink, e);
+    if (e) atomicOr(err, e);
 }
 
 // ---- shade: one step of trace_inner's state machine ---------------------------------
@@ -1072,7 +1087,7 @@ struct PtxContext {
     uint32_t fb_w = 0, fb_h = 0; bool fb_adaptive = false;
     float *fb_sum = nullptr, *fb_sum_sq = nullptr; uint32_t* fb_counts = nullptr;
 
-    bool packet_primary = true, packet_batch = false;   // PTX_PACKET_PRIMARY (0 disables), PTX_PACKET_BATCH (tests: ptx_trace_batch through the packet kernel)
+    bool packet_primary = true, packet_shadow = false, packet_batch = false;   // PTX_PACKET_SHADOW=1: the first shadow launch as packets too (measured: 132 -> 137 ms, its queue interleaves sun and sky rays)   // PTX_PACKET_PRIMARY (0 disables), PTX_PACKET_BATCH (tests: ptx_trace_batch through the packet kernel)
     uint32_t adaptive_batch = 32;   // adaptive passes traced together by ptx_fb_adaptive_passes (PTX_ADAPTIVE_BATCH)
     bool counting = false, profiling = false;
     struct Ev { hipEvent_t a, b; int cls; };
@@ -1337,7 +1352,10 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
         {
             ScopedEvent ev(ctx, CLS_SHADOW);
             const int sg = (int)std::min<uint64_t>(TRACE_GRID, (2ull * n + TRACE_BLOCK - 1) / TRACE_BLOCK);
-            if (ctx->counting) hipLaunchKernelGGL(k_shadow<true>, dim3(sg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q_shadow, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+            if (it == 0 && coherent && ctx->packet_shadow && !ctx->counting)
+                hipLaunchKernelGGL(k_shadow_packet, dim3(std::min(sg, PACKET_GRID)), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q_shadow, c, ctx->ovf, ctx->d_err,
+                                   ctx->S.nodes, ctx->S.tris, ctx->S.inst_tlas, ctx->S.inst, ctx->S.tlas_prims);
+            else if (ctx->counting) hipLaunchKernelGGL(k_shadow<true>, dim3(sg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q_shadow, c, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL(k_shadow<false>, dim3(sg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q_shadow, c, ctx->ovf, ctx->d_counters, ctx->d_err);
         }
         {
@@ -1394,6 +1412,7 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
         if (v) c->max_paths_in_flight = v;
     }
     if (const char* e = std::getenv("PTX_PACKET_PRIMARY")) c->packet_primary = std::strtoul(e, nullptr, 10) != 0;
+    if (const char* e = std::getenv("PTX_PACKET_SHADOW")) c->packet_shadow = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("PTX_PACKET_BATCH")) c->packet_batch = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("PTX_ADAPTIVE_BATCH")) {
         const unsigned long v = std::strtoul(e, nullptr, 10);
@@ -2006,11 +2025,13 @@ int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t
         uint32_t* d_work = ctx->ctrs[MAX_ITERS - 3].w_extend;   // spare counter block as the batch cursor
         if (hipMemsetAsync(&ctx->ctrs[MAX_ITERS - 3], 0, sizeof(IterCtr), ctx->stream) != hipSuccess) { st = fail(ctx, PTX_ERR_HIP, "memset failed"); break; }
         ScopedEvent* ev = new ScopedEvent(ctx, mode == PTX_TRACE_ANY ? CLS_SHADOW : CLS_EXTEND);
-        if (mode == PTX_TRACE_ANY) {
+        if (mode == PTX_TRACE_ANY && ctx->packet_batch && !ctx->counting) {
+            hipLaunchKernelGGL(k_trace_batch_packet<true>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_err);
+        } else if (mode == PTX_TRACE_ANY) {
             if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
         } else if (ctx->packet_batch && !ctx->counting) {
-            hipLaunchKernelGGL(k_trace_batch_packet, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, d_work, ctx->ovf, ctx->d_err);
+            hipLaunchKernelGGL(k_trace_batch_packet<false>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_err);
         } else {
             if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);

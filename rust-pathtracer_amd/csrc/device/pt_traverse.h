@@ -511,7 +511,7 @@ PT_DEV uint2 pk_read(const StackRef& s, int i) {
 #define PT_PACKET_CHUNK 8
 #endif
 constexpr uint32_t PACKET_CHUNK = PT_PACKET_CHUNK;
-template <class Src, class Sink>
+template <bool ANY, class Src, class Sink>
 PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes, const TriRec* __restrict__ g_tris,
                           const InstRec* __restrict__ g_inst_tlas, const InstRec* __restrict__ g_inst, const uint32_t* __restrict__ g_tlas_prims,
                           const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink, uint32_t& err) {
@@ -563,7 +563,7 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                     V3 wo, wd;
                     float unused_tmax;
                     src.fetch(key, &wo, &wd, &unused_tmax);
-                    if (m_tri != PTX_MISS) {
+                    if (!ANY && m_tri != PTX_MISS) {
                         const float4* p = reinterpret_cast<const float4*>(&g_inst[cur_inst]);
                         const float4 ma = p[5], mb = p[6], mc = p[7];
                         const V3 local_hit_point = o + ct * d;
@@ -584,7 +584,9 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
             }
             const uint2 e = pk_read(st, sp);
             const uint32_t word = __builtin_amdgcn_readfirstlane(e.x);
-            const bool act = !(__uint_as_float(e.y) >= ct);          // the pop-time cull (accel/bvh.rs:327-329), per ray
+            // closest: the pop-time cull (accel/bvh.rs:327-329), per ray; any-hit never culls (accel/bvh.rs:387-389): a ray takes
+            // part in the entries it pushed (distance below +inf) until it has found its hit
+            const bool act = ANY ? (!found && e.y != POS_INF_BITS) : !(__uint_as_float(e.y) >= ct);
             if (__ballot(act) == 0ull) continue;
             if (sp + 6 > CAPACITY) { err = 1u; found = false; sp = 0; break; }
             if (word & LEAF_FLAG) {
@@ -606,8 +608,10 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                         const float t = f * dot(edge2, q);
                         const bool hit = !(fabsf(a) < 1e-8f) && (u >= 0.0f && u <= 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
                                          (t >= tmin && t <= PT_INF);
-                        if (act && hit && t < ct) { ct = t; m_tri = __float_as_uint(tc.y); m_u = u; m_v = v; }
+                        if (ANY) { if (act && hit) found = true; }
+                        else if (act && hit && t < ct) { ct = t; m_tri = __float_as_uint(tc.y); m_u = u; m_v = v; }
                     }
+                    if (ANY && __ballot(valid && !found) == 0ull) { sp = 0; break; }     // every ray of the packet is occluded
                 } else {
                     // TLAS leaf: this primitive now, the rest afterwards and uncullable (the reference's inner loop)
                     if (count > 1u) pk_write(st, sp++, LEAF_FLAG | ((count - 2u) << PRIM_COUNT_SHIFT) | (start + 1u), act ? NEG_INF_BITS : POS_INF_BITS);
@@ -622,7 +626,7 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                     bool bhit;
                     if (__ballot(act && lexact) != 0ull) bhit = box_test<true>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
                     else bhit = box_test<false>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
-                    const bool enter = act && bhit && !(tb_enter >= PT_INF);
+                    const bool enter = act && bhit && (ANY || !(tb_enter >= PT_INF));
                     const unsigned long long em = __ballot(enter);
                     if (em == 0ull) continue;
                     // park the world level under a marker entry and descend into the mesh BVH

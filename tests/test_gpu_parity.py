@@ -101,6 +101,7 @@ def test_packet_traversal_bit_exact(pkg, oracle_det, scenes, monkeypatch, name, 
         c = osc.trace_closest(rays)
         g = lp.trace_closest(sc, rays)
         assert np.array_equal(c.view(np.uint8), g.view(np.uint8))
+        assert np.array_equal(osc.trace_any(rays), lp.trace_any(sc, rays)), "hit_any differs"      # any-hit packets
 
 
 def test_axis_aligned_rays_nan_slabs(pkg, loop, oracle_det, scenes):
