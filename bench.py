@@ -204,7 +204,7 @@ def main():
                                        "algorithmic_bytes_per_launch": round(pk_bytes),
                                        "achieved": round(pk_bytes / (pk_ms * 1e-3) / 1e9, 2), "unit": "GB/s"}
     traffic_file = os.path.join(ROOT, "profiles", "extend_traffic.json")
-    if os.path.exists(traffic_file):
+    if world == 1 and os.path.exists(traffic_file):      # measured on the 1-GPU frame's launches; null for a split frame
         try:
             roofline["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
         except Exception:
