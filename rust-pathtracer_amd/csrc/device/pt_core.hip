@@ -1684,7 +1684,12 @@ static int32_t render_to_images(PtxContext* ctx, uint32_t w, uint32_t h, uint32_
             hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->cam, ctx->P, ctx->wl_pixel, (const uint32_t*)nullptr,
                                (const uint32_t*)nullptr, sample_index, n, w, h, ctx->q[0], ctx->ctrs, 0u, (PtxRay*)nullptr, 0u);
             const int tg = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
-            hipLaunchKernelGGL(k_extend<false>, dim3(tg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q[0], ctx->ctrs, ctx->ovf, ctx->d_counters, ctx->d_err);
+            // the preview is primary rays only, one 8x8 tile per wave: packets
+            if (ctx->packet_primary)
+                hipLaunchKernelGGL(k_extend_packet, dim3(std::min(tg, PACKET_GRID)), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q[0], ctx->ctrs, ctx->ovf, ctx->d_err,
+                                   ctx->S.nodes, ctx->S.tris, ctx->S.inst_tlas, ctx->S.inst, ctx->S.tlas_prims);
+            else
+                hipLaunchKernelGGL(k_extend<false>, dim3(tg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q[0], ctx->ctrs, ctx->ovf, ctx->d_counters, ctx->d_err);
             hipLaunchKernelGGL(k_unshaded, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->P, n, d_rgb);
         }
     } else {
