@@ -266,13 +266,28 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S
 __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_extend_packet(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
                                                                uint32_t* err, const NodeRec* __restrict__ g_nodes, const TriRec* __restrict__ g_tris,
                                                                const InstRec* __restrict__ g_inst_tlas, const InstRec* __restrict__ g_inst,
-                                                               const uint32_t* __restrict__ g_tlas_prims) {
+                                                               const uint32_t* __restrict__ g_tlas_prims, int capacity, uint32_t* redo_keys,
+                                                               IterCtr* redo_ctr) {
     const StackRef st = make_stack(ovf);
     uint32_t e = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
-    trace_packets<false>(S, g_nodes, g_tris, g_inst_tlas, g_inst, g_tlas_prims, st, ctr->w_extend, ctr->n_active, src, sink, e);
+    trace_packets<false>(S, g_nodes, g_tris, g_inst_tlas, g_inst, g_tlas_prims, st, ctr->w_extend, ctr->n_active, src, sink, e, capacity,
+                         redo_keys, &redo_ctr->n_active);
     if (e) atomicOr(err, e);
+}
+// The rays of packets whose shared stack overflowed, traced one by one (normally none: the launch is a few waves
+// that find an empty queue).  Its own name so that profiles and timings keep k_extend's launches apart.
+__global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend_redo(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
+                                                             DevCounters* dc, uint32_t* err) {
+    const StackRef st = make_stack(ovf);
+    LaneCnt lc = {0, 0, 0, 0, 0, 0};
+    uint32_t nrays = 0, e = 0;
+    ExtendSrc src{P, q};
+    ExtendSink sink{P};
+    trace_queue<false, false>(S, st, ctr->w_extend, ctr->n_active, src, sink, lc, nrays, e);
+    if (e) atomicOr(err, e);
+    (void)dc;
 }
 template <bool ANY>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_trace_batch_packet(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
@@ -1067,7 +1082,8 @@ struct PtxContext {
     uint64_t capacity = 0;
     PathArrays P{};
     std::vector<void*> path_allocs;
-    uint32_t *q[2] = {nullptr, nullptr}, *q_shadow = nullptr, *q_final = nullptr;
+    uint32_t *q[2] = {nullptr, nullptr}, *q_shadow = nullptr, *q_final = nullptr, *q_redo = nullptr;
+    int packet_capacity = PACKET_LDS + OVF_STACK;   // PTX_PACKET_CAPACITY (tests): smaller packet stacks, to exercise the redo path
     IterCtr* ctrs = nullptr;
     uint2* ovf = nullptr;
     uint32_t* d_err = nullptr;
@@ -1230,6 +1246,7 @@ static int32_t ensure_capacity(PtxContext* ctx, uint64_t n) {
     HIPCHK(dev_alloc(pool, &P.aov_n, n)); HIPCHK(dev_alloc(pool, &P.sample, n));
     HIPCHK(dev_alloc(pool, &ctx->q[0], n)); HIPCHK(dev_alloc(pool, &ctx->q[1], n));
     HIPCHK(dev_alloc(pool, &ctx->q_shadow, 2 * n)); HIPCHK(dev_alloc(pool, &ctx->q_final, n));
+    HIPCHK(dev_alloc(pool, &ctx->q_redo, n));
     ctx->capacity = n;
     return PTX_OK;
 }
@@ -1311,6 +1328,24 @@ static int32_t check_device_error(PtxContext* ctx) {
     return PTX_OK;
 }
 
+// Primary rays as packets (+ the per-ray pass over the rays of packets whose shared stack overflowed: normally none).
+static int32_t launch_primary_packets(PtxContext* ctx, const uint32_t* q, IterCtr* c, uint64_t n) {
+    IterCtr* redo = &ctx->ctrs[MAX_ITERS - 2];          // spare counter block
+    HIPCHK(hipMemsetAsync(redo, 0, sizeof(IterCtr), ctx->stream));
+    const int grid = (int)std::min<uint64_t>(PACKET_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
+    {
+        ScopedEvent ev(ctx, CLS_PACKET);
+        hipLaunchKernelGGL(k_extend_packet, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, q, c, ctx->ovf, ctx->d_err,
+                           ctx->S.nodes, ctx->S.tris, ctx->S.inst_tlas, ctx->S.inst, ctx->S.tlas_prims, ctx->packet_capacity, ctx->q_redo, redo);
+    }
+    {
+        ScopedEvent ev(ctx, CLS_OTHER);
+        hipLaunchKernelGGL(k_extend_redo, dim3((int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK)), dim3(TRACE_BLOCK), 0, ctx->stream,
+                           ctx->S, ctx->P, ctx->q_redo, redo, ctx->ovf, ctx->d_counters, ctx->d_err);
+    }
+    return PTX_OK;
+}
+
 // Trace n path slots that k_raygen is about to initialise from (wl_pixel, wl_sample | fb counts | uniform).
 static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32_t* wl_sample, const uint32_t* per_pixel_counts,
                          uint32_t uniform_sample, uint32_t n, uint32_t w, uint32_t h, uint32_t max_bounces, const Target& tg, bool aov,
@@ -1337,12 +1372,14 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
         {
             // primary rays of neighbouring queue entries are coherent (a pixel's samples, or an 8x8 tile): packets
             const bool packets = it == 0 && coherent && ctx->packet_primary && !ctx->counting;
-            ScopedEvent ev(ctx, packets ? CLS_PACKET : CLS_EXTEND);
-            if (packets)
-                hipLaunchKernelGGL(k_extend_packet, dim3((int)std::min<uint64_t>(PACKET_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK)), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_err,
-                                   ctx->S.nodes, ctx->S.tris, ctx->S.inst_tlas, ctx->S.inst, ctx->S.tlas_prims);
-            else if (ctx->counting) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
-            else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+            if (packets) {
+                st = launch_primary_packets(ctx, qa, c, n);
+                if (st != PTX_OK) return st;
+            } else {
+                ScopedEvent ev(ctx, CLS_EXTEND);
+                if (ctx->counting) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+            }
         }
         {
             ScopedEvent ev(ctx, CLS_SHADE);
@@ -1413,6 +1450,7 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
     }
     if (const char* e = std::getenv("PTX_PACKET_PRIMARY")) c->packet_primary = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("PTX_PACKET_SHADOW")) c->packet_shadow = std::strtoul(e, nullptr, 10) != 0;
+    if (const char* e = std::getenv("PTX_PACKET_CAPACITY")) c->packet_capacity = std::max(8, std::min((int)std::strtol(e, nullptr, 10), PACKET_LDS + OVF_STACK));
     if (const char* e = std::getenv("PTX_PACKET_BATCH")) c->packet_batch = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("PTX_ADAPTIVE_BATCH")) {
         const unsigned long v = std::strtoul(e, nullptr, 10);
@@ -1685,10 +1723,10 @@ static int32_t render_to_images(PtxContext* ctx, uint32_t w, uint32_t h, uint32_
                                (const uint32_t*)nullptr, sample_index, n, w, h, ctx->q[0], ctx->ctrs, 0u, (PtxRay*)nullptr, 0u);
             const int tg = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
             // the preview is primary rays only, one 8x8 tile per wave: packets
-            if (ctx->packet_primary)
-                hipLaunchKernelGGL(k_extend_packet, dim3(std::min(tg, PACKET_GRID)), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q[0], ctx->ctrs, ctx->ovf, ctx->d_err,
-                                   ctx->S.nodes, ctx->S.tris, ctx->S.inst_tlas, ctx->S.inst, ctx->S.tlas_prims);
-            else
+            if (ctx->packet_primary) {
+                const int32_t ps = launch_primary_packets(ctx, ctx->q[0], ctx->ctrs, n);
+                if (ps != PTX_OK) return ps;
+            } else
                 hipLaunchKernelGGL(k_extend<false>, dim3(tg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q[0], ctx->ctrs, ctx->ovf, ctx->d_counters, ctx->d_err);
             hipLaunchKernelGGL(k_unshaded, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->P, n, d_rgb);
         }

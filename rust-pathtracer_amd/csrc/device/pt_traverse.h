@@ -514,9 +514,9 @@ constexpr uint32_t PACKET_CHUNK = PT_PACKET_CHUNK;
 template <bool ANY, class Src, class Sink>
 PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes, const TriRec* __restrict__ g_tris,
                           const InstRec* __restrict__ g_inst_tlas, const InstRec* __restrict__ g_inst, const uint32_t* __restrict__ g_tlas_prims,
-                          const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink, uint32_t& err) {
+                          const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink, uint32_t& err,
+                          const int capacity = PACKET_LDS + OVF_STACK, uint32_t* redo_keys = nullptr, uint32_t* redo_count = nullptr) {
     constexpr uint32_t POS_INF_BITS = 0x7F800000u;
-    constexpr int CAPACITY = PACKET_LDS + OVF_STACK;
     const float tmin = RAY_EPSILON;
     const uint32_t lane = threadIdx.x & 63u;
     // PACKET_CHUNK packets per claim: one cursor bumped once per packet would serialise 2 M same-address atomics
@@ -552,6 +552,7 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
         uint32_t cur_inst = 0u, tri_base = 0u;
         bool in_mesh = false;
         int sp = 0, marker_sp = -1;
+        bool overflow = false;
         // Bvh8::traverse_closest: (root, 0.0) is popped first; a lane without a ray never takes part
         if (S.n_tlas_nodes != 0u) pk_write(st, sp++, S.tlas_root_word, valid ? 0u : POS_INF_BITS);
         while (sp > 0) {
@@ -588,7 +589,13 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
             // part in the entries it pushed (distance below +inf) until it has found its hit
             const bool act = ANY ? (!found && e.y != POS_INF_BITS) : !(__uint_as_float(e.y) >= ct);
             if (__ballot(act) == 0ull) continue;
-            if (sp + 6 > CAPACITY) { err = 1u; found = false; sp = 0; break; }
+            if (sp + 6 > capacity) {
+                // The packet's stack is the union of 64 rays' stacks and can outgrow what any one of them needs.  With a
+                // redo queue the packet's rays are handed to the per-ray kernel (which starts them from scratch and
+                // overwrites whatever this packet wrote); without one it is an error.
+                overflow = true;
+                break;
+            }
             if (word & LEAF_FLAG) {
                 const uint32_t start = word & PRIM_START_MASK;
                 const uint32_t count = ((word >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
@@ -676,7 +683,18 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                 if (any0 && (w0 & LEAF_FLAG)) pk_write(st, sp++, w0, h0 ? __float_as_uint(te0) : POS_INF_BITS);
             }
         }
-        if (valid) sink.done(key, found);
+        if (overflow) {
+            if (redo_keys) {
+                const unsigned long long vm = __ballot(valid);
+                uint32_t rb = 0;
+                if (lane == 0u) rb = atomicAdd(redo_count, (uint32_t)__popcll(vm));
+                rb = __builtin_amdgcn_readfirstlane(rb);
+                if (valid) redo_keys[rb + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u))] = key;
+            } else {
+                err = 1u;
+                if (valid) sink.done(key, false);
+            }
+        } else if (valid) sink.done(key, found);
     }
 }
 

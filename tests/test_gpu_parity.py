@@ -104,6 +104,24 @@ def test_packet_traversal_bit_exact(pkg, oracle_det, scenes, monkeypatch, name, 
         assert np.array_equal(osc.trace_any(rays), lp.trace_any(sc, rays)), "hit_any differs"      # any-hit packets
 
 
+@pytest.mark.parametrize("name,flags,detail,w,h,bounces", [SCENES[3], SCENES[4], SCENES[7]])
+def test_packet_stack_overflow_falls_back_to_per_ray(pkg, oracle_det, scenes, monkeypatch, name, flags, detail, w, h, bounces):
+    """A packet's stack is the union of its rays' stacks; when it outgrows its capacity the packet's rays are redone by
+    the per-ray kernel.  With the capacity cut to 10 entries most packets take that road: the image must not change."""
+    monkeypatch.setenv("PTX_PACKET_CAPACITY", "10")
+    lp = pkg.HipRenderLoop(0)                      # reads PTX_PACKET_CAPACITY at creation
+    sc = scenes(name, flags, detail)
+    cam = sc.default_camera(w / h)
+    c = oracle_det.scene(sc).render_pass(cam, w, h, 1, bounces)
+    g = lp.render_pass(sc, cam, pkg.PathTracer(bounces), w, h, 1)
+    assert np.array_equal(bits(c), bits(g))
+    fb = pkg.DeviceFramebuffer(lp, w, h, adaptive=True)          # a pixel-major batch of 8 passes
+    fb.render_passes(sc, cam, pkg.PathTracer(bounces), 0, 8)
+    ofb = OracleFramebuffer(oracle_det.scene(sc), w, h, True)
+    ofb.render_passes(cam, 0, 8, bounces)
+    assert np.array_equal(bits(ofb.read()[0]), bits(fb.read()[0]))
+
+
 def test_axis_aligned_rays_nan_slabs(pkg, loop, oracle_det, scenes):
     """Rays with zero direction components whose origin lies on slab planes of axis-aligned walls:
     0 * inf = NaN inside the node test; the x86 min_ps/max_ps NaN rules decide the outcome."""
