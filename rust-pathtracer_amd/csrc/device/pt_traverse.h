@@ -66,7 +66,7 @@ namespace ptd {
 #define PT_REFILL_MIN_IDLE 16
 #endif
 #ifndef PT_REFILL_MIN_IDLE_ANY
-#define PT_REFILL_MIN_IDLE_ANY 32
+#define PT_REFILL_MIN_IDLE_ANY 40
 #endif
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 6
