@@ -93,6 +93,10 @@ constexpr uint32_t REFILL_MIN_IDLE = PT_REFILL_MIN_IDLE, REFILL_MIN_IDLE_ANY = P
 #define PT_TH_EXIT PT_RUN_THRESHOLD
 #endif
 constexpr uint32_t TH_NODE = PT_TH_NODE, TH_TRI = PT_TH_TRI, TH_ENTER = PT_TH_ENTER, TH_EXIT = PT_TH_EXIT;
+#ifndef PT_RUN_THRESHOLD_ANY
+#define PT_RUN_THRESHOLD_ANY 6
+#endif
+constexpr uint32_t TH_ANY = PT_RUN_THRESHOLD_ANY;   // any-hit traversals: one threshold for all four actions
 constexpr uint32_t RUN_THRESHOLD = PT_RUN_THRESHOLD;  // a non-majority action also runs with this many lanes waiting
 constexpr uint32_t NEG_INF_BITS = 0xFF800000u;
 constexpr uint32_t MARK_INST_MASK = 0x00FFFFFFu;      // marker word: instance id | MARK_EXACT
@@ -442,16 +446,16 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
             if (exhausted) break;
             continue;
         }
-        if (cx == mx || cx >= TH_EXIT) {
+        if (cx == mx || cx >= (ANY ? TH_ANY : TH_EXIT)) {
             if (tv.act == ACT_EXIT) tv.do_exit(S, st, lc, src, sink, my);
         }
-        if (ce == mx || ce >= TH_ENTER) {
+        if (ce == mx || ce >= (ANY ? TH_ANY : TH_ENTER)) {
             if (tv.act == ACT_ENTER) tv.do_enter(S, st, lc);
         }
         // Triangle and node lanes fetch their records together and wait once: the two sections used to pay one
         // memory round trip each, and a wave spends more time waiting on these loads than issuing.
-        const bool f_tri = (ctn == mx || ctn >= TH_TRI) && tv.act == ACT_TRI;
-        const bool f_node = (cn == mx || cn >= TH_NODE) && tv.act == ACT_NODE;
+        const bool f_tri = (ctn == mx || ctn >= (ANY ? TH_ANY : TH_TRI)) && tv.act == ACT_TRI;
+        const bool f_node = (cn == mx || cn >= (ANY ? TH_ANY : TH_NODE)) && tv.act == ACT_NODE;
         // wave-uniform choice of the node-visit variant: x86 NaN rule only if some lane can produce NaNs,
         // fourth child only if some lane's record has one
         const bool wave_special = __ballot(f_node && (tv.exact || (tv.pw >> NODE_NCHILD_SHIFT) == 3u)) != 0ull;
