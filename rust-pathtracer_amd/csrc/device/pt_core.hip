@@ -1390,7 +1390,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
         }
         {
             ScopedEvent ev(ctx, CLS_SHADE);
-            if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(SHADE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
+            if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, dim3(final_grid), dim3(SHADE_BLOCK)   /* counted: few blocks, each ends with 7 counter atomics per wave */, 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
             else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(SHADE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
         }
         {
