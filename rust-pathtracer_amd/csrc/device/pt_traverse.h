@@ -63,7 +63,7 @@ namespace ptd {
 #define PT_LDS_STACK 12
 #endif
 #ifndef PT_REFILL_MIN_IDLE
-#define PT_REFILL_MIN_IDLE 16
+#define PT_REFILL_MIN_IDLE 13
 #endif
 #ifndef PT_REFILL_MIN_IDLE_ANY
 #define PT_REFILL_MIN_IDLE_ANY 40
