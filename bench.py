@@ -7,9 +7,10 @@ Metric (BASELINE.json): Mrays/s + s/frame, Bistro 1080p 64 spp, 1/2/4/8 MI355X,
 A "step" is one whole frame: `for sample in 0..spp { render_pass; accumulate }`
 (main.rs:124-133) on the device-resident framebuffer, scene already in HBM.
 With N > 1 the frame is split by interleaved 8x8 pixel tiles (scene replicated)
-and the per-pixel sum / sum_sq / count buffers are combined with one RCCL
-all-reduce per frame (every rank contributes zeros outside its tiles, so the
-combined buffers are bit-identical to the single-GPU ones).  Total work is
+and the per-pixel sum / sum_sq / count records of every rank's own tiles are
+exchanged with ONE RCCL all-gather per frame and scattered into each rank's
+framebuffer (ownership is disjoint, so the combined buffers are bit-identical
+to the single-GPU ones).  Total work is
 fixed as N grows: "scaling": "strong".
 
 Prints ONE JSON line on rank 0.
@@ -107,24 +108,15 @@ def main():
     loop._bind(scene, cam)   # upload once: inputs are resident in HBM before anything is timed
     note(f"scene built in {build_s:.1f} s and uploaded")
 
-    if world > 1:
-        d_sum = torch.empty(h * w * 3, dtype=torch.float32, device="cuda")
-        d_sq = torch.empty(h * w * 3, dtype=torch.float32, device="cuda")
-        d_cnt = torch.empty(h * w, dtype=torch.int32, device="cuda")
+    exchange = pkg.render.TileExchange(dist, loop, w, h, rank, world, host_staged=(backend != "nccl")) if world > 1 else None
 
     def frame(r=None):
         fb.reset()
         fb.render_passes(scene, cam, r or renderer, 0, spp)
         if world > 1:
-            fb.export_dev(d_sum.data_ptr(), d_sq.data_ptr(), d_cnt.data_ptr())
-            loop.sync()                       # library stream -> visible to torch's stream
-            if backend == "nccl":
-                pkg.render.combine_framebuffers(dist, (d_sum, d_sq, d_cnt))   # RCCL over xGMI: disjoint tiles + zeros => exact
-            else:                             # rehearsal: gloo reduces host copies
-                for t in (d_sum, d_sq, d_cnt):
-                    c = t.cpu()
-                    dist.all_reduce(c)
-                    t.copy_(c)
+            # the one exchange step of the frame: all-gather of every rank's owned tiles (RCCL over xGMI), scattered
+            # into each rank's framebuffer, which then holds the whole frame (bit-identical to the 1-GPU frame)
+            exchange.combine(fb)
 
     def fence():
         loop.sync()
@@ -177,6 +169,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the timed frames check themselves (outside the timed region) ----------------------------------------
+    # fb.stats() goes through ptx_fb_stats, which reports a traversal stack overflow in any launch since the last
+    # check (a ray cut short is less work: a frame like that must not produce a number)
+    mn, mx, total = fb.stats()
+    s_sum, s_sq, s_cnt = fb.read()
+    owned = s_cnt > 0
+    n_owned = int(owned.sum())
+    want_owned = w * h          # after the exchange every rank's framebuffer holds the whole frame
+    verify = {
+        "status": "PTX_OK",
+        "counts_eq_spp": bool(mn == spp and mx == spp and n_owned == want_owned and (s_cnt[owned] == spp).all()),
+        "finite": bool(np.isfinite(s_sum).all() and np.isfinite(s_sq).all() and float(s_sum.min()) >= 0.0),
+        "clamped": bool(float(s_sum.max()) <= 10.0 * spp * (1 + 1e-6)),          # clamp_radiance: max component <= 10
+        "mean_radiance": round(float(s_sum.sum(dtype=np.float64)) / max(1, n_owned * spp * 3), 6),
+        "sum_sha256_16": __import__("hashlib").sha256(s_sum.tobytes()).hexdigest()[:16],
+    }
+    if not (verify["counts_eq_spp"] and verify["finite"] and verify["clamped"]):
+        raise SystemExit(f"bench.py: the timed frame failed its own checks: {verify}")
+
     sec_per_frame = elapsed / args.steps
     rays_per_frame = cnt["rays_closest"] + cnt["rays_any"]
     primary_per_frame = w * h * spp
@@ -193,8 +204,12 @@ def main():
     # rank 0 traced 1/world of the frame's extend work (tile interleave): per-launch bytes on this rank
     ext_bytes_launch = per_ray_bytes / world * args.steps / ext_launches
     achieved = ext_bytes_launch / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+    # `achieved` / `frac` are the SURVEY §8(d) contract: the REFERENCE's byte stream (every ray charged for every record
+    # it touches) over the measured launch time.  L1/L2 serve most of that stream, so it is not HBM utilisation:
+    # `traffic` / `measured_hbm_frac` (PMC counters) are, and `limiters` names what actually binds the kernel.
     roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "measured_hbm_frac": None,
+                "frac_meaning": "algorithmic (reference byte stream, SURVEY 8d) bytes / launch time / 8 TB/s; NOT HBM utilisation, see measured_hbm_frac and limiters",
                 "algorithmic_bytes_per_launch": round(ext_bytes_launch), "avg_launch_ms": round(ext_ms, 4),
                 "launches": int(ext_launches)}
     if pk_launches:
@@ -203,12 +218,24 @@ def main():
         roofline["primary_packets"] = {"kernel": "k_extend_packet", "launches": pk_launches, "avg_launch_ms": round(pk_ms, 4),
                                        "algorithmic_bytes_per_launch": round(pk_bytes),
                                        "achieved": round(pk_bytes / (pk_ms * 1e-3) / 1e9, 2), "unit": "GB/s"}
-    traffic_file = os.path.join(ROOT, "profiles", "extend_traffic.json")
-    if world == 1 and os.path.exists(traffic_file):      # measured on the 1-GPU frame's launches; null for a split frame
+    # PMC-derived figures come from the committed profile of ONE configuration: attach them only when this run is that
+    # configuration (otherwise a Cornell run would carry Bistro's traffic)
+    this_config = {"scene": args.scene, "detail": args.detail, "width": w, "height": h, "spp": spp, "bounces": args.bounces,
+                   "flags": args.flags, "seed": args.seed, "world": world}
+    lim_file = os.path.join(ROOT, "profiles", "r02_limiters.json")
+    if os.path.exists(lim_file):
         try:
-            roofline["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+            lim = json.load(open(lim_file))
+            k = lim.get("kernels", {}).get("k_extend<false>")
+            if lim.get("config") == this_config and k:
+                roofline["traffic"] = k["hbm_bytes_per_launch"]
+                # counter bytes over THIS run's launch time
+                roofline["measured_hbm_frac"] = round(k["hbm_bytes_per_launch"] / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                roofline["limiters"] = {n: k[n] for n in ("hbm_traffic_frac", "l2_bw_frac", "valu_issue_frac", "lanes_active",
+                                                         "mem_wait_share", "binding") if n in k}
+                roofline["limiters"]["source"] = lim.get("source")
+        except Exception as e:      # a malformed profile file must not fail the bench
+            roofline["limiters_error"] = str(e)
 
     out = {
         "metric": "Mrays/s (all ray types) on Bistro-like 1080p 64spp; s/frame = ms_per_step/1000",
@@ -218,15 +245,16 @@ def main():
         "config": {"workload": f"{args.scene} (procedural stand-in, seed {args.seed}, detail {args.detail}) "
                                f"{w}x{h} {spp}spp PathTracer<{args.bounces}> env-map IS + sun + MIS, tile-interleaved over {world} GPU(s)",
                    "triangles": scene.stats()["triangles"], "instances": scene.stats()["instances"],
-                   "parallelism": f"tiles8x8 mod {world}" + (" + RCCL all-reduce" if world > 1 else "")},
+                   "parallelism": f"tiles8x8 mod {world}" + (" + one RCCL all-gather of owned tiles per frame" if world > 1 else "")},
         "sec_per_frame": round(sec_per_frame, 4),
         "mprimary_per_s": round(primary_per_frame / sec_per_frame / 1e6, 2),
         "rays_per_frame": rays_per_frame,
         "algorithmic_bytes_per_frame": abytes_frame,
-        "frame_hbm_frac": round(abytes_frame / sec_per_frame / 1e9 / HBM_PEAK_GBS, 5),
+        "frame_reference_stream_frac": round(abytes_frame / sec_per_frame / 1e9 / HBM_PEAK_GBS, 5),   # reference byte stream / 8 TB/s: can exceed 1 (caches)
         "kernel_ms_per_frame": {k: round(tim[k] / args.steps, 3) for k in
                                 ("raygen_ms", "packet_ms", "extend_ms", "shade_ms", "shadow_ms", "accumulate_ms")},
         "scene_build_s": round(build_s, 2),
+        "verify": verify,
         "roofline": roofline,
     }
 

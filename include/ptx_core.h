@@ -336,6 +336,17 @@ int32_t ptx_fb_tonemap_srgb8(PtxContext* ctx, int32_t tonemap, float exposure, u
  * on the library stream; call ptx_sync before another stream reads it. */
 int32_t ptx_fb_export_dev(PtxContext* ctx, float* d_sum, float* d_sum_sq, uint32_t* d_counts);
 
+/* The one exchange step of a multi-GPU frame (no counterpart in the reference, which is one process): a rank's own
+ * 8x8 tiles (ptx_set_partition) as packed 28-byte records (sum.xyz, sum_sq.xyz, count; 64 records per tile, zero
+ * records for pixels outside the image and for the tail when this rank owns one tile fewer than rank 0), written to
+ * caller-owned DEVICE memory of ptx_fb_tiles_bytes(width, height, world) bytes — the same size on every rank, so
+ * one all-gather (RCCL over xGMI) moves them; ptx_fb_import_tiles_dev then scatters rank `src_rank`'s block into this
+ * context's framebuffer, which ends up holding the whole frame, bit-identical to a single-GPU frame.  Both calls are
+ * ordered on the library stream and not synchronised (ptx_sync before another stream touches the buffers). */
+uint64_t ptx_fb_tiles_bytes(uint32_t width, uint32_t height, uint32_t world);
+int32_t ptx_fb_export_tiles_dev(PtxContext* ctx, void* d_out, uint64_t capacity_bytes);
+int32_t ptx_fb_import_tiles_dev(PtxContext* ctx, const void* d_in, uint32_t src_rank, uint32_t world);
+
 /* One whole frame in one call: the `for sample` loop of `run_benchmark`
  * (src/main.rs:123-141) and, with `adaptive` non-NULL, the progressive loop of
  * `App::render_fullres_frame` (raytracer/app.rs:195-236): `spp` uniform passes
@@ -375,6 +386,19 @@ int32_t ptx_debug_math(PtxContext* ctx, int32_t fn, const float* x, const float*
 int32_t ptx_set_counting(PtxContext* ctx, int32_t enabled);   /* counted kernels are slower */
 int32_t ptx_reset_counters(PtxContext* ctx);
 int32_t ptx_get_counters(PtxContext* ctx, PtxCounters* out);
+
+/* Which traversal paths the launches since the last ptx_reset_counters exercised (no counterpart in the reference,
+ * whose stacks are fixed 64-entry arrays, accel/bvh.rs:320,379): the deepest per-ray stack (all three BVH levels of
+ * one ray share one typed stack; recorded by the counted kernels only), the deepest packet stack, and how many rays
+ * were handed from a packet whose shared stack overflowed to the per-ray kernel.  A high-water mark above
+ * lds_stack_entries / packet_lds_entries means the HBM spill strips were used. */
+typedef struct PtxDebugStats {
+    uint32_t trace_stack_high_water;
+    uint32_t packet_stack_high_water;
+    uint64_t packet_redo_rays;
+    uint32_t lds_stack_entries, packet_lds_entries, packet_capacity, _pad;
+} PtxDebugStats;
+int32_t ptx_get_debug_stats(PtxContext* ctx, PtxDebugStats* out);
 
 int32_t ptx_set_profiling(PtxContext* ctx, int32_t enabled);
 int32_t ptx_reset_timings(PtxContext* ctx);

@@ -151,6 +151,11 @@ class PtxFrameStats(C.Structure):
                 ("uniform_passes", c_u32), ("adaptive_passes", c_u32), ("adaptive_samples", c_u64)]
 
 
+class PtxDebugStats(C.Structure):
+    _fields_ = [("trace_stack_high_water", c_u32), ("packet_stack_high_water", c_u32), ("packet_redo_rays", c_u64),
+                ("lds_stack_entries", c_u32), ("packet_lds_entries", c_u32), ("packet_capacity", c_u32), ("_pad", c_u32)]
+
+
 class PtxTimings(C.Structure):
     _fields_ = [
         ("raygen_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double),

@@ -59,6 +59,10 @@ struct PathArrays {
 // (the queue cursors are arrays: one per queue segment, see trace_queue)
 struct IterCtr { uint32_t n_active, n_shadow, n_final, pad0; uint32_t w_extend[QUEUE_SEGMENTS], w_shadow[QUEUE_SEGMENTS]; };
 constexpr uint32_t MAX_ITERS = 4096;
+// counter blocks past the per-iteration range [0, MAX_ITERS): one per helper, so none aliases an iteration's block or
+// another helper's
+constexpr uint32_t CTR_REDO = MAX_ITERS, CTR_STATS = MAX_ITERS + 1, CTR_BATCH = MAX_ITERS + 2, CTR_ADAPTIVE = MAX_ITERS + 3,
+                   CTR_BLOCKS = MAX_ITERS + 4;
 // P.rad[].w = pixel index | which pending contributions of the previous step are stored (an absent one is +0.0: it is
 // neither written nor read back, which is most of them — the BSDF-sampled sun term almost always, the NEE terms whenever
 // the light is below the surface)
@@ -144,6 +148,10 @@ PT_DEV void flush_lane_cnt(DevCounters* dc, const LaneCnt& lc, uint32_t rays, bo
     wave_add(&dc->v[C_TRI_TESTS], lc.tri_tests);
     wave_add(&dc->v[C_INST_ENTRIES], lc.inst_entries);
     wave_add(&dc->v[C_INST_HITS], lc.inst_hits);
+    { uint32_t hw = lc.stack_hw;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor(hw, off); hw = o > hw ? o : hw; }
+      if ((threadIdx.x & 63u) == 0u && hw) atomicMax(&dc->dbg[0], hw); }
     if (any) {
         wave_add(&dc->v[C_ANY_NODE_VISITS], lc.node_visits);
         wave_add(&dc->v[C_ANY_NODE_CHILDREN], lc.node_children);
@@ -182,7 +190,7 @@ template <bool ANY, bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
                                                              uint8_t* out_any, uint32_t* work, uint2* ovf, DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, e = 0;
     BatchSrc src{rays};
     BatchSink<ANY> sink{out_hits, out_any};
@@ -256,7 +264,7 @@ template <bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, e = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
@@ -270,13 +278,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_extend_packet(Sc
                                                                uint32_t* err, const NodeRec* __restrict__ g_nodes, const TriRec* __restrict__ g_tris,
                                                                const InstRec* __restrict__ g_inst_tlas, const InstRec* __restrict__ g_inst,
                                                                const uint32_t* __restrict__ g_tlas_prims, int capacity, uint32_t* redo_keys,
-                                                               IterCtr* redo_ctr) {
+                                                               IterCtr* redo_ctr, DevCounters* dc) {
     const StackRef st = make_stack(ovf);
     uint32_t e = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
     trace_packets<false>(S, g_nodes, g_tris, g_inst_tlas, g_inst, g_tlas_prims, st, ctr->w_extend, ctr->n_active, src, sink, e, capacity,
-                         redo_keys, &redo_ctr->n_active);
+                         redo_keys, &redo_ctr->n_active, &dc->dbg[1]);
     if (e) atomicOr(err, e);
 }
 // The rays of packets whose shared stack overflowed, traced one by one (normally none: the launch is a few waves
@@ -284,22 +292,23 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_extend_packet(Sc
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend_redo(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
                                                              DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, e = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
     trace_queue<false, false>(S, st, ctr->w_extend, ctr->n_active, src, sink, lc, nrays, e);
     if (e) atomicOr(err, e);
-    (void)dc;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ctr->n_active)     // measurement: rays that took the redo road
+        atomicAdd(reinterpret_cast<unsigned long long*>(&dc->dbg[2]), (unsigned long long)ctr->n_active);
 }
 template <bool ANY>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_trace_batch_packet(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
-                                                                    uint8_t* out_any, uint32_t* work, uint2* ovf, uint32_t* err) {
+                                                                    uint8_t* out_any, uint32_t* work, uint2* ovf, uint32_t* err, DevCounters* dc) {
     const StackRef st = make_stack(ovf);
     uint32_t e = 0;
     BatchSrc src{rays};
     BatchSink<ANY> sink{out_hits, out_any};
-    trace_packets<ANY>(S, S.nodes, S.tris, S.inst_tlas, S.inst, S.tlas_prims, st, work, n, src, sink, e);
+    trace_packets<ANY>(S, S.nodes, S.tris, S.inst_tlas, S.inst, S.tlas_prims, st, work, n, src, sink, e, PACKET_LDS + OVF_STACK, nullptr, nullptr, &dc->dbg[1]);
     if (e) atomicOr(err, e);
 }
 
@@ -331,7 +340,7 @@ template <bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_shadow(SceneDev S, PathArrays P, const uint32_t* qs, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, e = 0;
     ShadowSrc src{S, P, qs};
     ShadowSink sink{P};
@@ -981,6 +990,41 @@ __global__ void k_mean(const float* sum, const uint32_t* counts, uint32_t n_pixe
     else { const float cf = (float)c; out[f] = sum[f] / cf; out[f + 1] = sum[f + 1] / cf; out[f + 2] = sum[f + 2] / cf; }
 }
 
+// ---- multi-GPU exchange: a rank's own 8x8 tiles as packed records, and back -------------------------------------
+// Record = 7 words (sum.xyz, sum_sq.xyz, count); tile k of a rank (global tile index rank + k * world) occupies records
+// [64 k, 64 k + 64) in row-major order inside the tile; pixels outside the image are zero records.
+__global__ void k_export_tiles(const float* sum, const float* sum_sq, const uint32_t* counts, uint32_t w, uint32_t h, uint32_t rank,
+                               uint32_t world, uint32_t n_tiles_rank, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tiles_rank * 64u) return;
+    const uint32_t tx_n = (w + 7u) / 8u;
+    const uint32_t t = rank + (i >> 6) * world, l = i & 63u;
+    const uint32_t x = (t % tx_n) * 8u + (l & 7u), y = (t / tx_n) * 8u + (l >> 3);
+    uint32_t r[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (x < w && y < h) {
+        const size_t p = (size_t)y * w + x;
+        r[0] = __float_as_uint(sum[3 * p]); r[1] = __float_as_uint(sum[3 * p + 1]); r[2] = __float_as_uint(sum[3 * p + 2]);
+        if (sum_sq) { r[3] = __float_as_uint(sum_sq[3 * p]); r[4] = __float_as_uint(sum_sq[3 * p + 1]); r[5] = __float_as_uint(sum_sq[3 * p + 2]); }
+        r[6] = counts[p];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) out[(size_t)i * 7 + k] = r[k];
+}
+__global__ void k_import_tiles(float* sum, float* sum_sq, uint32_t* counts, uint32_t w, uint32_t h, uint32_t rank, uint32_t world,
+                               uint32_t n_tiles_rank, const uint32_t* in) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tiles_rank * 64u) return;
+    const uint32_t tx_n = (w + 7u) / 8u;
+    const uint32_t t = rank + (i >> 6) * world, l = i & 63u;
+    const uint32_t x = (t % tx_n) * 8u + (l & 7u), y = (t / tx_n) * 8u + (l >> 3);
+    if (x >= w || y >= h) return;
+    const size_t p = (size_t)y * w + x;
+    const uint32_t* r = in + (size_t)i * 7;
+    sum[3 * p] = __uint_as_float(r[0]); sum[3 * p + 1] = __uint_as_float(r[1]); sum[3 * p + 2] = __uint_as_float(r[2]);
+    if (sum_sq) { sum_sq[3 * p] = __uint_as_float(r[3]); sum_sq[3 * p + 1] = __uint_as_float(r[4]); sum_sq[3 * p + 2] = __uint_as_float(r[5]); }
+    counts[p] = r[6];
+}
+
 // ---- upload time: pack one mesh's shading triangles (pt_types.h ShadeTri) -------------------------
 __global__ void k_build_shade_tris(SceneDev S, MeshRec m, ShadeTri* out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1287,6 +1331,7 @@ static int32_t ensure_worklist(PtxContext* ctx, uint32_t w, uint32_t h) {
     return PTX_OK;
 }
 
+constexpr uint32_t SSS_POLL_EVERY = 8;
 enum { CLS_RAYGEN = 0, CLS_EXTEND, CLS_SHADE, CLS_SHADOW, CLS_ACCUM, CLS_OTHER, CLS_PACKET };
 struct ScopedEvent {
     PtxContext* ctx; int idx = -1;
@@ -1333,13 +1378,13 @@ static int32_t check_device_error(PtxContext* ctx) {
 
 // Primary rays as packets (+ the per-ray pass over the rays of packets whose shared stack overflowed: normally none).
 static int32_t launch_primary_packets(PtxContext* ctx, const uint32_t* q, IterCtr* c, uint64_t n) {
-    IterCtr* redo = &ctx->ctrs[MAX_ITERS - 2];          // spare counter block
+    IterCtr* redo = &ctx->ctrs[CTR_REDO];
     HIPCHK(hipMemsetAsync(redo, 0, sizeof(IterCtr), ctx->stream));
     const int grid = (int)std::min<uint64_t>(PACKET_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
     {
         ScopedEvent ev(ctx, CLS_PACKET);
         hipLaunchKernelGGL(k_extend_packet, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, q, c, ctx->ovf, ctx->d_err,
-                           ctx->S.nodes, ctx->S.tris, ctx->S.inst_tlas, ctx->S.inst, ctx->S.tlas_prims, ctx->packet_capacity, ctx->q_redo, redo);
+                           ctx->S.nodes, ctx->S.tris, ctx->S.inst_tlas, ctx->S.inst, ctx->S.tlas_prims, ctx->packet_capacity, ctx->q_redo, redo, ctx->d_counters);
     }
     {
         ScopedEvent ev(ctx, CLS_OTHER);
@@ -1355,8 +1400,21 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
                          uint32_t batch = 0) {
     if (n == 0) return PTX_OK;
     if ((uint64_t)w * h > PIXEL_MASK) return fail(ctx, PTX_ERR_UNSUPPORTED, "frames above 2^29 pixels are not supported");
+    // the bounce counter of a path is 8 bits wide (FL_BOUNCE_MASK); the reference's MAX_BOUNCES is 8 or 16
+    if (max_bounces > FL_BOUNCE_MASK) return fail(ctx, PTX_ERR_INVALID, "max_bounces above 255 is not supported");
     int32_t st = ensure_capacity(ctx, n);
     if (st != PTX_OK) return st;
+    if (max_bounces == 0) {
+        // `for bounce in 0..0` (pathtracer.rs:117): no ray is traced; every sample is clamp_radiance(0) = 0 and still counts
+        HIPCHK(hipMemsetAsync(ctx->ctrs, 0, sizeof(IterCtr), ctx->stream));
+        hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->cam, ctx->P, wl_pixel, wl_sample,
+                           per_pixel_counts, uniform_sample, n, w, h, ctx->q[0], ctx->ctrs, aov ? 1u : 0u, (PtxRay*)nullptr, batch);
+        HIPCHK(hipMemcpyAsync(&ctx->ctrs[0].n_final, &ctx->ctrs[0].n_active, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_finalize, dim3((int)std::min<uint64_t>(256 * 8, (n + SHADE_BLOCK - 1) / SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, ctx->stream,
+                           ctx->P, ctx->q[0], ctx->ctrs, tg, ctx->d_counters, ctx->counting ? 1u : 0u);
+        HIPCHK(hipGetLastError());
+        return PTX_OK;
+    }
     const bool sss = ctx->S.has_sss != 0;
     const uint32_t iter_cap = sss ? MAX_ITERS - 1 : std::min<uint32_t>(max_bounces, MAX_ITERS - 1);
     HIPCHK(hipMemsetAsync(ctx->ctrs, 0, sizeof(IterCtr) * (size_t)(sss ? MAX_ITERS : iter_cap + 1), ctx->stream));
@@ -1372,6 +1430,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
     // launch feels (383 -> 375 ms), and the kernel itself runs 5 % faster
     const int shade_grid = (int)std::min<uint64_t>((uint64_t)256 * PT_SHADE_GRID_PER_CU, (n + SHADE_BLOCK - 1) / SHADE_BLOCK);
     const int final_grid = (int)std::min<uint64_t>(256 * 8, (n + SHADE_BLOCK - 1) / SHADE_BLOCK);
+    bool drained = false;
     for (uint32_t it = 0; it < iter_cap; ++it) {
         uint32_t* qa = ctx->q[it & 1];
         uint32_t* qb = ctx->q[(it + 1) & 1];
@@ -1406,14 +1465,20 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
             ScopedEvent ev(ctx, CLS_ACCUM);
             hipLaunchKernelGGL(k_finalize, dim3(final_grid), dim3(SHADE_BLOCK), 0, ctx->stream, ctx->P, ctx->q_final, c, tg, ctx->d_counters, ctx->counting ? 1u : 0u);
         }
-        if (sss && it + 1 >= max_bounces) {
-            // subsurface walks make the iteration count data dependent: poll the live count
+        if (sss && it + 1 >= max_bounces && ((it + 1 - max_bounces) % SSS_POLL_EVERY == 0u || it + 1 == iter_cap)) {
+            // subsurface walks make the iteration count data dependent: poll the live count every few iterations (the
+            // launches of an iteration whose queues are empty leave in microseconds; a host round trip per iteration
+            // does not)
             HIPCHK(hipMemcpyAsync(ctx->h_pinned + 1, &ctx->ctrs[it + 1].n_active, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            if (ctx->h_pinned[1] == 0) break;
+            if (ctx->h_pinned[1] == 0) { drained = true; break; }
         }
     }
     HIPCHK(hipGetLastError());
+    // Without SSS every path ends by iteration max_bounces (k_shade retires it at bounce >= max_bounces).  With SSS a
+    // path that is still walking after MAX_ITERS - 1 iterations would never reach k_finalize: refuse instead of
+    // returning a frame with samples missing.
+    if (sss && !drained) return fail(ctx, PTX_ERR_UNSUPPORTED, "paths still alive after 4095 wavefront iterations (subsurface walks x bounces)");
     if (ctx->counting) {
         // primary rays are counted on the host side of the launch: one per slot
         ctx->timings.other_ms += 0.0;
@@ -1464,7 +1529,7 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
         if (v) c->adaptive_batch = (uint32_t)std::min<unsigned long>(v, 256);
     }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * MAX_ITERS));
+    HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * CTR_BLOCKS));
     HIPCHK(hipMalloc((void**)&c->ovf, sizeof(uint2) * (size_t)std::max(TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
     HIPCHK(hipMalloc((void**)&c->d_err, 4));
     HIPCHK(hipMemset(c->d_err, 0, 4));
@@ -1706,8 +1771,7 @@ int32_t ptx_set_partition(PtxContext* ctx, uint32_t rank, uint32_t world) {
 
 int32_t ptx_sync(PtxContext* ctx) {
     REQUIRE_CTX();
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return PTX_OK;
+    return check_device_error(ctx);   // synchronises the library stream and reports a traversal stack overflow since the last check
 }
 
 static int32_t render_to_images(PtxContext* ctx, uint32_t w, uint32_t h, uint32_t sample_index, uint32_t max_bounces, float* out_rgb,
@@ -1843,7 +1907,8 @@ int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t co
         k += b;
     }
     add_primary_count(ctx, (uint64_t)ctx->wl_n * count);
-    return PTX_OK;
+    // a traversal that ran out of stack ends its ray early (less work, a faster frame): never hand that back as OK
+    return check_device_error(ctx);
 }
 
 int32_t ptx_fb_adaptive_pass(PtxContext* ctx, const PtxAdaptiveConfig* cfg, uint32_t max_bounces, uint64_t* out_rendered) {
@@ -1858,7 +1923,7 @@ int32_t ptx_fb_adaptive_pass(PtxContext* ctx, const PtxAdaptiveConfig* cfg, uint
     st = ensure_lists(ctx, n);
     if (st != PTX_OK) return st;
     uint32_t* keys = ctx->list_b; uint32_t* work = ctx->list_c;
-    uint32_t* d_count = reinterpret_cast<uint32_t*>(&ctx->ctrs[MAX_ITERS - 1]);   // spare counter block
+    uint32_t* d_count = reinterpret_cast<uint32_t*>(&ctx->ctrs[CTR_ADAPTIVE]);
     HIPCHK(hipMemsetAsync(d_count, 0, sizeof(IterCtr), ctx->stream));
     const int grid = (int)std::min<uint32_t>(2048, (n + 255) / 256);
     hipLaunchKernelGGL(k_noise_keys, dim3(grid), dim3(256), 0, ctx->stream, ctx->wl_pixel, n, ctx->fb_sum, ctx->fb_sum_sq, ctx->fb_counts,
@@ -1918,7 +1983,7 @@ int32_t ptx_fb_adaptive_passes(PtxContext* ctx, const PtxAdaptiveConfig* cfg, ui
     st = ensure_lists(ctx, n);
     if (st != PTX_OK) return st;
     uint32_t* keys = ctx->list_b; uint32_t* work = ctx->list_c;
-    uint32_t* d_count = reinterpret_cast<uint32_t*>(&ctx->ctrs[MAX_ITERS - 1]);   // spare counter block
+    uint32_t* d_count = reinterpret_cast<uint32_t*>(&ctx->ctrs[CTR_ADAPTIVE]);
     const int grid = (int)std::min<uint32_t>(2048, (n + 255) / 256);
     uint32_t passes = 0; uint64_t rendered = 0;
     while (passes < max_passes) {
@@ -1971,7 +2036,7 @@ int32_t ptx_fb_stats(PtxContext* ctx, uint32_t* out_min, uint32_t* out_max, uint
     if (!ctx->fb_sum) return fail(ctx, PTX_ERR_INVALID, "no framebuffer: call ptx_fb_reset");
     int32_t st = ensure_worklist(ctx, ctx->fb_w, ctx->fb_h);
     if (st != PTX_OK) return st;
-    uint32_t* d = reinterpret_cast<uint32_t*>(&ctx->ctrs[MAX_ITERS - 2]);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&ctx->ctrs[CTR_STATS]);
     const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
     HIPCHK(hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1982,7 +2047,7 @@ int32_t ptx_fb_stats(PtxContext* ctx, uint32_t* out_min, uint32_t* out_max, uint
     if (out_min) *out_min = ctx->wl_n ? ctx->h_pinned[4] : 0;
     if (out_max) *out_max = ctx->h_pinned[5];
     if (out_total) std::memcpy(out_total, ctx->h_pinned + 6, 8);
-    return PTX_OK;
+    return check_device_error(ctx);
 }
 
 int32_t ptx_fb_read(PtxContext* ctx, float* out_sum, float* out_sum_sq, uint32_t* out_counts) {
@@ -2030,6 +2095,39 @@ int32_t ptx_fb_export_dev(PtxContext* ctx, float* d_sum, float* d_sum_sq, uint32
     return PTX_OK;
 }
 
+// ---- multi-GPU exchange ---------------------------------------------------------------------
+static uint32_t tiles_of_rank(uint32_t w, uint32_t h, uint32_t rank, uint32_t world) {
+    const uint64_t n_tiles = (uint64_t)((w + 7) / 8) * ((h + 7) / 8);
+    return rank < n_tiles ? (uint32_t)((n_tiles - rank + world - 1) / world) : 0u;
+}
+uint64_t ptx_fb_tiles_bytes(uint32_t width, uint32_t height, uint32_t world) {
+    if (!world || !width || !height) return 0;
+    return (uint64_t)tiles_of_rank(width, height, 0, world) * 64u * 28u;     // rank 0 owns the most tiles
+}
+int32_t ptx_fb_export_tiles_dev(PtxContext* ctx, void* d_out, uint64_t capacity_bytes) {
+    REQUIRE_CTX();
+    if (!ctx->fb_sum) return fail(ctx, PTX_ERR_INVALID, "no framebuffer: call ptx_fb_reset");
+    const uint64_t need = ptx_fb_tiles_bytes(ctx->fb_w, ctx->fb_h, ctx->world);
+    if (!d_out || capacity_bytes < need) return fail(ctx, PTX_ERR_INVALID, "tile export buffer is null or smaller than ptx_fb_tiles_bytes");
+    const uint32_t nt = tiles_of_rank(ctx->fb_w, ctx->fb_h, ctx->rank, ctx->world);
+    // ranks with one tile fewer than rank 0: the tail stays zero (count 0), so that the gathered block has one size
+    if ((uint64_t)nt * 64u * 28u < need) HIPCHK(hipMemsetAsync((char*)d_out + (uint64_t)nt * 64u * 28u, 0, need - (uint64_t)nt * 64u * 28u, ctx->stream));
+    if (nt) hipLaunchKernelGGL(k_export_tiles, dim3((nt * 64u + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->fb_sum, ctx->fb_sum_sq, ctx->fb_counts,
+                               ctx->fb_w, ctx->fb_h, ctx->rank, ctx->world, nt, (uint32_t*)d_out);
+    HIPCHK(hipGetLastError());
+    return PTX_OK;
+}
+int32_t ptx_fb_import_tiles_dev(PtxContext* ctx, const void* d_in, uint32_t src_rank, uint32_t world) {
+    REQUIRE_CTX();
+    if (!ctx->fb_sum) return fail(ctx, PTX_ERR_INVALID, "no framebuffer: call ptx_fb_reset");
+    if (!d_in || !world || src_rank >= world) return fail(ctx, PTX_ERR_INVALID, "bad tile import arguments");
+    const uint32_t nt = tiles_of_rank(ctx->fb_w, ctx->fb_h, src_rank, world);
+    if (nt) hipLaunchKernelGGL(k_import_tiles, dim3((nt * 64u + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->fb_sum, ctx->fb_sum_sq, ctx->fb_counts,
+                               ctx->fb_w, ctx->fb_h, src_rank, world, nt, (const uint32_t*)d_in);
+    HIPCHK(hipGetLastError());
+    return PTX_OK;
+}
+
 // ---- parity / measurement ------------------------------------------------------------------
 int32_t ptx_render_frame(PtxContext* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_bounces,
                          const PtxAdaptiveConfig* adaptive, uint32_t max_spp, float* out_mean, uint32_t* out_counts,
@@ -2072,16 +2170,16 @@ int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t
     do {
         if (hipMemcpyAsync(d_rays, rays, n * sizeof(PtxRay), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = fail(ctx, PTX_ERR_HIP, "H2D copy failed"); break; }
         const int grid = (int)std::min<uint64_t>(TRACE_GRID, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
-        uint32_t* d_work = ctx->ctrs[MAX_ITERS - 3].w_extend;   // spare counter block as the batch cursor
-        if (hipMemsetAsync(&ctx->ctrs[MAX_ITERS - 3], 0, sizeof(IterCtr), ctx->stream) != hipSuccess) { st = fail(ctx, PTX_ERR_HIP, "memset failed"); break; }
+        uint32_t* d_work = ctx->ctrs[CTR_BATCH].w_extend;   // the batch cursor
+        if (hipMemsetAsync(&ctx->ctrs[CTR_BATCH], 0, sizeof(IterCtr), ctx->stream) != hipSuccess) { st = fail(ctx, PTX_ERR_HIP, "memset failed"); break; }
         ScopedEvent* ev = new ScopedEvent(ctx, mode == PTX_TRACE_ANY ? CLS_SHADOW : CLS_EXTEND);
         if (mode == PTX_TRACE_ANY && ctx->packet_batch && !ctx->counting) {
-            hipLaunchKernelGGL(k_trace_batch_packet<true>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_err);
+            hipLaunchKernelGGL(k_trace_batch_packet<true>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_err, ctx->d_counters);
         } else if (mode == PTX_TRACE_ANY) {
             if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
         } else if (ctx->packet_batch && !ctx->counting) {
-            hipLaunchKernelGGL(k_trace_batch_packet<false>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_err);
+            hipLaunchKernelGGL(k_trace_batch_packet<false>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_err, ctx->d_counters);
         } else {
             if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
@@ -2141,6 +2239,20 @@ int32_t ptx_get_counters(PtxContext* ctx, PtxCounters* out) {
     if (!out) return fail(ctx, PTX_ERR_INVALID, "null output");
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out, ctx->d_counters, sizeof(PtxCounters), hipMemcpyDeviceToHost));
+    return PTX_OK;
+}
+int32_t ptx_get_debug_stats(PtxContext* ctx, PtxDebugStats* out) {
+    REQUIRE_CTX();
+    if (!out) return fail(ctx, PTX_ERR_INVALID, "null output");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    unsigned int dbg[4];
+    HIPCHK(hipMemcpy(dbg, ctx->d_counters->dbg, sizeof(dbg), hipMemcpyDeviceToHost));
+    out->trace_stack_high_water = dbg[0];
+    out->packet_stack_high_water = dbg[1];
+    out->packet_redo_rays = (uint64_t)dbg[2] | ((uint64_t)dbg[3] << 32);
+    out->lds_stack_entries = (uint32_t)LDS_STACK;
+    out->packet_lds_entries = (uint32_t)PACKET_LDS;
+    out->packet_capacity = (uint32_t)ctx->packet_capacity;
     return PTX_OK;
 }
 int32_t ptx_set_profiling(PtxContext* ctx, int32_t enabled) { REQUIRE_CTX(); drain_events(ctx); ctx->profiling = enabled != 0; return PTX_OK; }

@@ -143,7 +143,7 @@ PT_DEV uint2 st_read(const StackRef& s, int i) {
     return v;
 }
 
-struct LaneCnt { uint32_t node_visits, node_children, prim_reads, tri_tests, inst_entries, inst_hits; };
+struct LaneCnt { uint32_t node_visits, node_children, prim_reads, tri_tests, inst_entries, inst_hits, stack_hw; };   // stack_hw: deepest stack this lane reached (counted kernels)
 
 PT_DEV V3 xf_point(const float4 a, const float4 b, const float4 c, V3 p) {
     // Mat4::transform_point3: ((x_axis*x + y_axis*y) + z_axis*z) + w_axis, packed columns
@@ -279,6 +279,7 @@ struct Traverser {
         if (h2) st_write(st, l2 ? lb + l3 : sp + i0 + i1, w2, __float_as_uint(te2));
         if (FOUR && h3) st_write(st, l3 ? lb : sp + i0 + i1 + i2, w3, __float_as_uint(te3));
         sp = lb + l0 + l1 + l2 + l3;
+        if (CNT) lc.stack_hw = (uint32_t)sp > lc.stack_hw ? (uint32_t)sp : lc.stack_hw;
     }
 
     // ---- ACT_TRI: intersect_triangle on the next primitive of the leaf ------------------
@@ -334,6 +335,7 @@ struct Traverser {
         st_write(st, sp++, __float_as_uint(inv.x), __float_as_uint(inv.y));
         st_write(st, sp++, __float_as_uint(inv.z), __float_as_uint(ct));
         st_write(st, sp++, inst_idx | (exact ? MARK_EXACT : 0u), NEG_INF_BITS);
+        if (CNT) lc.stack_hw = (uint32_t)sp > lc.stack_hw ? (uint32_t)sp : lc.stack_hw;
         in_mesh = true;
         ct = PT_INF;
         o = lo; d = ld; inv = linv;
@@ -519,13 +521,15 @@ template <bool ANY, class Src, class Sink>
 PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes, const TriRec* __restrict__ g_tris,
                           const InstRec* __restrict__ g_inst_tlas, const InstRec* __restrict__ g_inst, const uint32_t* __restrict__ g_tlas_prims,
                           const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink, uint32_t& err,
-                          const int capacity = PACKET_LDS + OVF_STACK, uint32_t* redo_keys = nullptr, uint32_t* redo_count = nullptr) {
+                          const int capacity = PACKET_LDS + OVF_STACK, uint32_t* redo_keys = nullptr, uint32_t* redo_count = nullptr,
+                          uint32_t* stack_hw = nullptr) {
     constexpr uint32_t POS_INF_BITS = 0x7F800000u;
     const float tmin = RAY_EPSILON;
     const uint32_t lane = threadIdx.x & 63u;
     // PACKET_CHUNK packets per claim: one cursor bumped once per packet would serialise 2 M same-address atomics
     // (~17 ns each) in a 133 M-ray launch
     uint32_t base = 0, chunk_left = 0;     // wave-uniform
+    int hw = 0;                            // deepest packet stack of this wave (wave-uniform)
     for (;;) {
         if (chunk_left == 0u) {
             uint32_t b = 0;
@@ -560,6 +564,7 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
         // Bvh8::traverse_closest: (root, 0.0) is popped first; a lane without a ray never takes part
         if (S.n_tlas_nodes != 0u) pk_write(st, sp++, S.tlas_root_word, valid ? 0u : POS_INF_BITS);
         while (sp > 0) {
+            hw = sp > hw ? sp : hw;
             --sp;
             if (in_mesh && sp == marker_sp) {
                 // ---- tail of Instance::hit (accel/mod.rs:128-137) for the lanes that entered
@@ -700,6 +705,8 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
             }
         } else if (valid) sink.done(key, found);
     }
+    // measurement only: most waves find a value at least as large already there and skip the atomic
+    if (stack_hw && lane == 0u && (uint32_t)hw > *stack_hw) atomicMax(stack_hw, (uint32_t)hw);
 }
 
 }  // namespace ptd

@@ -130,7 +130,12 @@ struct CameraDev {
 };
 
 // Per-wave event counters behind ptx_get_counters.
-struct DevCounters { unsigned long long v[sizeof(PtxCounters) / 8]; };
+struct DevCounters {
+    unsigned long long v[sizeof(PtxCounters) / 8];
+    // PtxDebugStats (not part of PtxCounters): [0] deepest per-ray stack (counted kernels), [1] deepest packet stack,
+    // [2..3] rays handed from overflowed packets to k_extend_redo (u64)
+    unsigned int dbg[4];
+};
 enum CounterId {
     C_RAYS_CLOSEST, C_RAYS_ANY, C_NODE_VISITS, C_NODE_CHILDREN, C_PRIM_INDEX_READS, C_TRI_TESTS,
     C_INST_ENTRIES, C_INST_HITS, C_HITDATA, C_MATERIAL, C_TEXTURE, C_CDF_PROBES, C_SKY_PDF,

@@ -23,6 +23,7 @@ EXPORTS = [
     "ptx_fb_read_mean", "ptx_fb_export_dev", "ptx_sync", "ptx_trace_batch", "ptx_generate_primary_rays",
     "ptx_set_counting", "ptx_reset_counters", "ptx_get_counters", "ptx_set_profiling", "ptx_reset_timings",
     "ptx_get_timings", "ptx_debug_math", "ptx_render_frame", "ptx_fb_tonemap_srgb8", "ptx_fb_adaptive_passes",
+    "ptx_get_debug_stats", "ptx_fb_tiles_bytes", "ptx_fb_export_tiles_dev", "ptx_fb_import_tiles_dev",
 ]
 
 
@@ -74,9 +75,15 @@ def lib():
     L.ptx_reset_timings.argtypes = [vp]
     L.ptx_get_timings.argtypes = [vp, C.POINTER(abi.PtxTimings)]
     L.ptx_debug_math.argtypes = [vp, i32, vp, vp, u64, vp]
+    L.ptx_get_debug_stats.argtypes = [vp, C.POINTER(abi.PtxDebugStats)]
+    L.ptx_fb_tiles_bytes.argtypes = [u32, u32, u32]
+    L.ptx_fb_export_tiles_dev.argtypes = [vp, vp, u64]
+    L.ptx_fb_import_tiles_dev.argtypes = [vp, vp, u32, u32]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name != "ptx_last_error":
+        if name == "ptx_fb_tiles_bytes":
+            fn.restype = u64
+        elif name != "ptx_last_error":
             fn.restype = i32
     _lib = L
     return L
@@ -269,6 +276,12 @@ class HipRenderLoop:
         self._check(self.L.ptx_get_counters(self._h, C.byref(c)), "ptx_get_counters")
         return c.as_dict()
 
+    def debug_stats(self):
+        """Stack high-water marks and packet-redo count since the last `reset_counters` (which traversal paths ran)."""
+        d = abi.PtxDebugStats()
+        self._check(self.L.ptx_get_debug_stats(self._h, C.byref(d)), "ptx_get_debug_stats")
+        return {n: int(getattr(d, n)) for n, _ in abi.PtxDebugStats._fields_ if n != "_pad"}
+
     def set_profiling(self, on):
         self._check(self.L.ptx_set_profiling(self._h, 1 if on else 0), "ptx_set_profiling")
 
@@ -304,6 +317,81 @@ def combine_framebuffers(dist, buffers):
     for b in buffers:
         dist.all_reduce(b)
     return buffers
+
+
+def tiles_bytes(width, height, world):
+    """Bytes of one rank's packed tile block (`ptx_fb_tiles_bytes`): the same on every rank."""
+    return int(lib().ptx_fb_tiles_bytes(width, height, world))
+
+
+def pack_tiles(width, height, rank, world, sum_, sum_sq, counts):
+    """Host mirror of `ptx_fb_export_tiles_dev` (numpy, for the CPU tests of the exchange): rank's tiles as
+    (n_tiles_max * 64, 7) uint32 records."""
+    tx_n, ty_n = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    n_max = -(-(tx_n * ty_n) // world)
+    out = np.zeros((n_max * 64, 7), dtype=np.uint32)
+    t = np.arange(rank, tx_n * ty_n, world, dtype=np.int64)
+    ly, lx = np.meshgrid(np.arange(TILE), np.arange(TILE), indexing="ij")
+    x = (t % tx_n)[:, None] * TILE + lx.reshape(-1)[None, :]
+    y = (t // tx_n)[:, None] * TILE + ly.reshape(-1)[None, :]
+    ok = (x < width) & (y < height)
+    rec = np.nonzero(ok.reshape(-1))[0]
+    p = (y * width + x)[ok]
+    out[rec, 0:3] = np.ascontiguousarray(sum_, dtype=np.float32).reshape(-1, 3)[p].view(np.uint32)
+    if sum_sq is not None:
+        out[rec, 3:6] = np.ascontiguousarray(sum_sq, dtype=np.float32).reshape(-1, 3)[p].view(np.uint32)
+    out[rec, 6] = np.ascontiguousarray(counts, dtype=np.uint32).reshape(-1)[p]
+    return out
+
+
+def unpack_tiles(width, height, src_rank, world, block, sum_, sum_sq, counts):
+    """Host mirror of `ptx_fb_import_tiles_dev`: scatter `src_rank`'s block into full-size host buffers in place."""
+    tx_n, ty_n = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    t = np.arange(src_rank, tx_n * ty_n, world, dtype=np.int64)
+    ly, lx = np.meshgrid(np.arange(TILE), np.arange(TILE), indexing="ij")
+    x = (t % tx_n)[:, None] * TILE + lx.reshape(-1)[None, :]
+    y = (t // tx_n)[:, None] * TILE + ly.reshape(-1)[None, :]
+    ok = (x < width) & (y < height)
+    rec = np.nonzero(ok.reshape(-1))[0]
+    p = (y * width + x)[ok]
+    block = np.asarray(block, dtype=np.uint32).reshape(-1, 7)
+    sum_.reshape(-1, 3)[p] = block[rec, 0:3].view(np.float32)
+    if sum_sq is not None:
+        sum_sq.reshape(-1, 3)[p] = block[rec, 3:6].view(np.float32)
+    counts.reshape(-1)[p] = block[rec, 6]
+
+
+class TileExchange:
+    """The one collective of a multi-GPU frame: ONE all-gather of every rank's owned-tile records.
+
+    `combine(fb)`: export this rank's tiles into a device buffer, all-gather the equal-sized blocks (RCCL over xGMI;
+    `host_staged` = gloo rehearsal on a one-GPU box), scatter the other ranks' blocks into this rank's framebuffer.
+    At 1080p the gathered buffer is 58 MB in total and every rank receives (world-1)/world of it — against three
+    full-frame all-reduces (3 x 58 MB through a ring, 7/8 of it zeros at 8 ranks) before."""
+
+    def __init__(self, dist, loop, width, height, rank, world, host_staged=False):
+        import torch
+        self.dist, self.loop, self.rank, self.world, self.host_staged = dist, loop, rank, world, host_staged
+        self.nbytes = tiles_bytes(width, height, world)
+        self.torch = torch
+        self.send = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
+        self.recv = torch.empty(self.nbytes * world, dtype=torch.uint8, device="cuda")
+
+    def combine(self, fb):
+        torch, L, h = self.torch, self.loop.L, self.loop._h
+        torch.cuda.current_stream().synchronize()      # the previous frame's collective no longer reads `send`
+        self.loop._check(L.ptx_fb_export_tiles_dev(h, self.send.data_ptr(), self.nbytes), "ptx_fb_export_tiles_dev")
+        self.loop.sync()                               # library stream -> visible to torch's stream
+        if self.host_staged:
+            parts = [torch.empty(self.nbytes, dtype=torch.uint8) for _ in range(self.world)]
+            self.dist.all_gather(parts, self.send.cpu())
+            self.recv.copy_(torch.cat(parts))
+        else:
+            self.dist.all_gather_into_tensor(self.recv, self.send)
+        torch.cuda.current_stream().synchronize()      # the library stream reads `recv` next
+        for r in range(self.world):
+            if r != self.rank:
+                self.loop._check(L.ptx_fb_import_tiles_dev(h, self.recv.data_ptr() + r * self.nbytes, r, self.world), "ptx_fb_import_tiles_dev")
 
 
 def render_frame_distributed(all_reduce_max, loop, fb, scene, camera, renderer, spp, adaptive=None, max_spp=0):

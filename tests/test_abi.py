@@ -32,7 +32,7 @@ def test_host_library_exports_every_declared_symbol(pkg):
 def test_struct_sizes_match_the_c_compiler(pkg):
     abi = pkg._abi
     names = ["PtxBvh8Node", "PtxBvh8", "PtxMesh", "PtxInstance", "PtxMaterial", "PtxTexture", "PtxSky", "PtxSun",
-             "PtxBlueNoise", "PtxSceneDesc", "PtxCamera", "PtxRay", "PtxHitRecord", "PtxCounters", "PtxAdaptiveConfig", "PtxTimings", "PtxFrameStats"]
+             "PtxBlueNoise", "PtxSceneDesc", "PtxCamera", "PtxRay", "PtxHitRecord", "PtxCounters", "PtxAdaptiveConfig", "PtxTimings", "PtxFrameStats", "PtxDebugStats"]
     src = '#include "ptx_core.h"\n#include <stdio.h>\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:

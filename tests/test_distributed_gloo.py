@@ -1,7 +1,8 @@
-"""The N > 1 path on CPU: two gloo ranks, each renders only the 8x8 tiles it owns (scene replicated), then the
-framebuffers are combined with the same `combine_framebuffers` all-reduce bench.py uses over RCCL.  The pixel work is
-done by the oracle here (no GPU in this tier); what is under test is the partition + exchange logic: the combined
-buffers must be bit-identical to a single-rank frame."""
+"""The N > 1 path on CPU: two gloo ranks, each renders only the 8x8 tiles it owns (scene replicated), then the ranks
+exchange their owned-tile records with ONE all-gather — the exchange bench.py runs over RCCL (`TileExchange`), here
+with the numpy mirrors of `ptx_fb_export_tiles_dev` / `ptx_fb_import_tiles_dev` (`pack_tiles` / `unpack_tiles`; a GPU
+test checks the kernels against these mirrors).  The pixel work is done by the oracle here (no GPU in this tier); what
+is under test is the partition + exchange logic: the combined buffers must be bit-identical to a single-rank frame."""
 import os
 import socket
 import sys
@@ -45,10 +46,23 @@ def _worker(rank, world, port, w, h, spp, bounces, out_dir):
         s[owned] += px
         q[owned] += px * px
         c[owned] += 1
-    ts, tq, tc = torch.from_numpy(s), torch.from_numpy(q), torch.from_numpy(c)
+    # one all-gather of equal-sized blocks of packed owned-tile records, then scatter the other ranks' blocks
+    mine = pkg.render.pack_tiles(w, h, rank, world, s, q, c.astype(np.uint32))
+    assert mine.nbytes == pkg.render.tiles_bytes(w, h, world)
+    blocks = [torch.empty(mine.nbytes, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(blocks, torch.from_numpy(mine.view(np.uint8).reshape(-1)))
+    cu = c.astype(np.uint32)
+    for r in range(world):
+        if r != rank:
+            pkg.render.unpack_tiles(w, h, r, world, blocks[r].numpy().view(np.uint32), s, q, cu)
+    # the all-reduce form of the same exchange (every rank contributes zeros outside its tiles) must agree
+    s2, q2, c2 = np.zeros_like(s), np.zeros_like(q), np.zeros_like(c)
+    s2[owned], q2[owned], c2[owned] = s[owned], q[owned], c[owned]
+    ts, tq, tc = torch.from_numpy(s2), torch.from_numpy(q2), torch.from_numpy(c2)
     pkg.render.combine_framebuffers(dist, (ts, tq, tc))
+    assert np.array_equal(ts.numpy().view(np.uint32), s.view(np.uint32)) and np.array_equal(tc.numpy(), cu.astype(np.int32))
     if rank == 0:
-        np.savez(os.path.join(out_dir, "combined.npz"), s=ts.numpy(), q=tq.numpy(), c=tc.numpy(), n_owned=len(owned))
+        np.savez(os.path.join(out_dir, "combined.npz"), s=s, q=q, c=cu.astype(np.int32), n_owned=len(owned))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,7 +83,7 @@ def test_partition_is_disjoint_and_complete(pkg):
 def test_two_rank_gloo_frame_equals_single_rank(pkg, oracle_det, tmp_path):
     import torch.multiprocessing as mp
     from oracle_py import OracleFramebuffer
-    w, h, spp, bounces, world = 48, 27, 3, 8, 2
+    w, h, spp, bounces, world = 52, 27, 3, 8, 2      # not multiples of 8: ragged edge tiles, odd tile count
     port = _free_port()
     mp.spawn(_worker, args=(world, port, w, h, spp, bounces, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "combined.npz")

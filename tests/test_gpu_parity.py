@@ -547,6 +547,46 @@ def test_tile_partition_sums_to_whole_frame(pkg, loop, scenes):
     assert np.array_equal(acc[2], whole[2]) and np.array_equal(bits(acc[0]), bits(whole[0])) and np.array_equal(bits(acc[1]), bits(whole[1]))
 
 
+def test_tile_exchange_kernels_match_host_mirror(pkg, loop, scenes):
+    """ptx_fb_export_tiles_dev / ptx_fb_import_tiles_dev (the blocks one RCCL all-gather moves) against the numpy mirrors
+    the 2-rank gloo test exchanges; three virtual ranks rebuild the whole frame in a fourth context, bit for bit."""
+    from hip_ctypes import Hip
+    sc = scenes("cornell", 1, 1.0)
+    w, h, world = 100, 52, 3          # ragged edge tiles; 91 tiles: rank 0 owns one more than rank 2
+    cam = sc.default_camera(w / h)
+    fb = pkg.DeviceFramebuffer(loop, w, h, adaptive=True)
+    fb.render_passes(sc, cam, pkg.PathTracer(8), 0, 3)
+    whole = fb.read()
+    nbytes = pkg.render.tiles_bytes(w, h, world)
+    assert nbytes == -(-(13 * 7) // world) * 64 * 28
+    hip = Hip()
+    try:
+        blocks = []
+        for r in range(world):
+            loop.set_partition(r, world)
+            fb.reset()
+            fb.render_passes(sc, cam, pkg.PathTracer(8), 0, 3)
+            d = hip.malloc(nbytes)
+            loop._check(loop.L.ptx_fb_export_tiles_dev(loop._h, d, nbytes), "export")
+            loop.sync()
+            got = hip.download(d, np.uint32, nbytes // 4).reshape(-1, 7)
+            part = fb.read()
+            assert np.array_equal(got, pkg.render.pack_tiles(w, h, r, world, *part)), f"rank {r}: export differs from the host mirror"
+            blocks.append(d)
+        loop.set_partition(0, 1)
+        fb.reset()                       # an empty framebuffer receives every rank's block
+        for r in range(world):
+            loop._check(loop.L.ptx_fb_import_tiles_dev(loop._h, blocks[r], r, world), "import")
+        got = fb.read()
+        for a, b in zip(got, whole):
+            assert np.array_equal(bits(a), bits(b))
+        with pytest.raises(pkg.RenderCoreError):
+            loop._check(loop.L.ptx_fb_export_tiles_dev(loop._h, blocks[0], nbytes - 1), "export")
+    finally:
+        loop.set_partition(0, 1)
+        hip.release()
+
+
 def test_image_within_tolerance_of_libm_oracle(pkg, loop, oracle_libm, scenes):
     """The reference-faithful comparison: the oracle with glibc transcendentals (what rustc's f32 methods call)."""
     for name, flags, detail, bounces in (("sponza_like", 1, 0.05, 16), ("sss_test", 1, 0.3, 16)):
