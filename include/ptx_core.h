@@ -373,6 +373,18 @@ int32_t ptx_sync(PtxContext* ctx);
 int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t mode,
                         PtxHitRecord* out_hits, uint8_t* out_any);
 
+/* ptx_trace_batch for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  It has no counterpart in the reference.  Same kernels and same results as ptx_trace_batch, but:
+ * `d_rays` and the output are caller-owned DEVICE memory, and the scratch the kernels need (queue cursors, error word,
+ * per-lane traversal-stack spill strips) is a file-scope device array of 34.6 MB per GPU inside the library instead of
+ * a hipMalloc — the call makes no hipMalloc / hipFree / allocating library call.  At most PTX_NOALLOC_MAX_RAYS rays per
+ * call (more is PTX_ERR_INVALID); the launch uses 512 persistent waves, so it is slower than ptx_trace_batch on large
+ * batches.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two contexts, two threads)
+ * race.  Returns after the results are complete (synchronises the library stream). */
+#define PTX_NOALLOC_MAX_RAYS (1u << 24)
+int32_t ptx_trace_batch_noalloc(PtxContext* ctx, const PtxRay* d_rays, uint64_t n, int32_t mode,
+                                PtxHitRecord* d_out_hits, uint8_t* d_out_any);
+
 /* The primary rays `render_pixel` would generate (renderloop/parallel.rs:31-56,
  * bluenoise.rs:156-172, camera.rs:66-95), for the RNG-seed parity check. */
 int32_t ptx_generate_primary_rays(PtxContext* ctx, uint32_t width, uint32_t height,

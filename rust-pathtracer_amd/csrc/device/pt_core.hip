@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1160,6 +1161,20 @@ struct PtxContext {
 
 static std::string g_last_error;
 
+// ---- ptx_trace_batch_noalloc: the one entry point that allocates nothing -------------------------------------
+// Its kernels are ptx_trace_batch's; what that call takes from the context's allocations (queue cursors, error word,
+// per-lane stack spill strips) lives in this file-scope device array instead, one copy per GPU, held until the process
+// ends.  Host code never uses the array's name as an address: ptx_create resolves it once per device with
+// hipGetSymbolAddress and everything below goes through that pointer.
+constexpr int NOALLOC_WAVES = 512;                       // persistent waves of a no-alloc launch (2 per CU)
+constexpr size_t NOALLOC_HEAD = 256;                     // [0, 32) queue cursors, [64, 68) error word
+constexpr size_t NOALLOC_ERR_OFFSET = 64;
+constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_HEAD + sizeof(uint2) * (size_t)NOALLOC_WAVES * TRACE_BLOCK * OVF_STACK;   // 34.6 MB
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES];   // per device: each GPU holds its own copy at its own address
+static std::mutex g_scratch_mutex;
+
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \
         hipError_t e_ = (expr);                                                                               \
@@ -1527,6 +1542,15 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
     if (const char* e = std::getenv("PTX_ADAPTIVE_BATCH")) {
         const unsigned long v = std::strtoul(e, nullptr, 10);
         if (v) c->adaptive_batch = (uint32_t)std::min<unsigned long>(v, 256);
+    }
+    if (device_index < NOALLOC_MAX_DEVICES) {
+        // once per device, with that device current (set above)
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device_index]) {
+            void* p = nullptr;
+            HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            g_scratch_ptr[device_index] = static_cast<unsigned char*>(p);
+        }
     }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * CTR_BLOCKS));
@@ -2191,6 +2215,37 @@ int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_rays); (void)hipFree(d_out);
     return st;
+}
+
+int32_t ptx_trace_batch_noalloc(PtxContext* ctx, const PtxRay* d_rays, uint64_t n, int32_t mode, PtxHitRecord* d_out_hits,
+                                uint8_t* d_out_any) {
+    REQUIRE_SCENE();
+    if (n == 0) return PTX_OK;
+    if (n > PTX_NOALLOC_MAX_RAYS) return fail(ctx, PTX_ERR_INVALID, "ptx_trace_batch_noalloc: more than PTX_NOALLOC_MAX_RAYS (2^24) rays in one call");
+    if (!d_rays || (mode == PTX_TRACE_CLOSEST && !d_out_hits) || (mode == PTX_TRACE_ANY && !d_out_any) || (mode != PTX_TRACE_CLOSEST && mode != PTX_TRACE_ANY))
+        return fail(ctx, PTX_ERR_INVALID, "bad trace_batch arguments");
+    unsigned char* base = ctx->device < NOALLOC_MAX_DEVICES ? g_scratch_ptr[ctx->device] : nullptr;
+    if (!base) return fail(ctx, PTX_ERR_UNSUPPORTED, "no scratch array resolved for this device");
+    uint32_t* d_work = reinterpret_cast<uint32_t*>(base);
+    uint32_t* d_err = reinterpret_cast<uint32_t*>(base + NOALLOC_ERR_OFFSET);
+    uint2* d_ovf = reinterpret_cast<uint2*>(base + NOALLOC_HEAD);
+    // the array keeps the last call's contents: cursors and error word must start at zero (stack strips are written
+    // before they are read)
+    HIPCHK(hipMemsetAsync(base, 0, NOALLOC_HEAD, ctx->stream));
+    const int grid = (int)std::min<uint64_t>(NOALLOC_WAVES, (n + TRACE_BLOCK - 1) / TRACE_BLOCK);
+    if (mode == PTX_TRACE_ANY) {
+        if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, d_out_any, d_work, d_ovf, ctx->d_counters, d_err);
+        else hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, d_out_any, d_work, d_ovf, ctx->d_counters, d_err);
+    } else {
+        if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, d_out_hits, (uint8_t*)nullptr, d_work, d_ovf, ctx->d_counters, d_err);
+        else hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, d_out_hits, (uint8_t*)nullptr, d_work, d_ovf, ctx->d_counters, d_err);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ctx->h_pinned + 12, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pinned[12] != 0)
+        return fail(ctx, PTX_ERR_STACK_OVERFLOW, "traversal stack exceeded 64 entries on one BVH level (the reference would panic)");
+    return PTX_OK;
 }
 
 int32_t ptx_generate_primary_rays(PtxContext* ctx, uint32_t w, uint32_t h, uint32_t sample_index, PtxRay* out_rays) {

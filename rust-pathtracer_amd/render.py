@@ -23,7 +23,7 @@ EXPORTS = [
     "ptx_fb_read_mean", "ptx_fb_export_dev", "ptx_sync", "ptx_trace_batch", "ptx_generate_primary_rays",
     "ptx_set_counting", "ptx_reset_counters", "ptx_get_counters", "ptx_set_profiling", "ptx_reset_timings",
     "ptx_get_timings", "ptx_debug_math", "ptx_render_frame", "ptx_fb_tonemap_srgb8", "ptx_fb_adaptive_passes",
-    "ptx_get_debug_stats", "ptx_fb_tiles_bytes", "ptx_fb_export_tiles_dev", "ptx_fb_import_tiles_dev",
+    "ptx_get_debug_stats", "ptx_trace_batch_noalloc", "ptx_fb_tiles_bytes", "ptx_fb_export_tiles_dev", "ptx_fb_import_tiles_dev",
 ]
 
 
@@ -76,6 +76,7 @@ def lib():
     L.ptx_get_timings.argtypes = [vp, C.POINTER(abi.PtxTimings)]
     L.ptx_debug_math.argtypes = [vp, i32, vp, vp, u64, vp]
     L.ptx_get_debug_stats.argtypes = [vp, C.POINTER(abi.PtxDebugStats)]
+    L.ptx_trace_batch_noalloc.argtypes = [vp, vp, u64, i32, vp, vp]
     L.ptx_fb_tiles_bytes.argtypes = [u32, u32, u32]
     L.ptx_fb_export_tiles_dev.argtypes = [vp, vp, u64]
     L.ptx_fb_import_tiles_dev.argtypes = [vp, vp, u32, u32]
@@ -249,6 +250,13 @@ class HipRenderLoop:
         if len(rays):
             self._check(self.L.ptx_trace_batch(self._h, _p(rays), len(rays), abi.PTX_TRACE_ANY, None, _p(out)), "ptx_trace_batch")
         return out
+
+    def trace_batch_noalloc(self, scene, d_rays_ptr, n, mode, d_out_hits_ptr=None, d_out_any_ptr=None):
+        """`ptx_trace_batch_noalloc`: rays and results are caller-owned device memory (raw pointers, e.g. torch
+        `data_ptr()`); the call allocates nothing.  mode: abi.PTX_TRACE_CLOSEST / abi.PTX_TRACE_ANY."""
+        self._bind(scene, None)
+        self._check(self.L.ptx_trace_batch_noalloc(self._h, d_rays_ptr, int(n), int(mode), d_out_hits_ptr, d_out_any_ptr),
+                    "ptx_trace_batch_noalloc")
 
     def primary_rays(self, scene, camera, width, height, sample_index):
         self._bind(scene, camera)
