@@ -37,9 +37,11 @@ enum {
     PTX_ERR_NO_DEVICE = 2,    /* no HIP device / device index out of range      */
     PTX_ERR_HIP = 3,          /* a HIP runtime call failed                      */
     PTX_ERR_NO_SCENE = 4,     /* render/trace before ptx_upload_scene           */
-    PTX_ERR_STACK_OVERFLOW = 5, /* a traversal needed > 64 stack entries on one
-                                   BVH level: the reference would panic on its
-                                   bounds check (accel/bvh.rs:320,361,379,408)  */
+    PTX_ERR_STACK_OVERFLOW = 5, /* a traversal needed more stack than a ray's device stack
+                                   holds (144 entries shared by the TLAS, Blas and mesh
+                                   levels).  The reference's arrays hold 64 entries per
+                                   level and panic beyond (accel/bvh.rs:320,361,379,408);
+                                   scenes it can trace need far less than 144              */
     PTX_ERR_UNSUPPORTED = 6
 };
 
@@ -242,6 +244,9 @@ typedef struct PtxTimings {
      * extend_ms / extend_launches are the per-ray kernel's alone */
     double packet_ms;
     uint64_t packet_launches;
+    /* the subsurface random-walk kernel (one launch per iteration in scenes with subsurface materials) */
+    double walk_ms;
+    uint64_t walk_launches;
 } PtxTimings;
 
 typedef struct PtxContext PtxContext;

@@ -162,6 +162,7 @@ class PtxTimings(C.Structure):
         ("shadow_ms", C.c_double), ("accumulate_ms", C.c_double), ("other_ms", C.c_double),
         ("extend_launches", c_u64), ("shade_launches", c_u64), ("shadow_launches", c_u64),
         ("packet_ms", C.c_double), ("packet_launches", c_u64),
+        ("walk_ms", C.c_double), ("walk_launches", c_u64),
     ]
 
 

@@ -32,7 +32,7 @@ using namespace ptd;
 namespace {
 
 // ============================================================== path state =====
-constexpr uint32_t ST_NORMAL = 0, ST_THICK = 1, ST_WALK = 2;
+constexpr uint32_t ST_NORMAL = 0, ST_THICK = 1, ST_WALK = 2;   // ST_THICK / ST_WALK paths live on the walk queue (k_sss_step)
 constexpr uint32_t FL_BOUNCE_MASK = 0xFFu, FL_SPECULAR = 1u << 8, FL_STATE_SHIFT = 9, FL_STATE_MASK = 3u << 9,
                    FL_FIRST_HIT = 1u << 11, FL_STEP_SHIFT = 16, FL_STEP_MASK = 0xFFu << 16;
 
@@ -58,7 +58,7 @@ struct PathArrays {
 
 // per-iteration counter block
 // (the queue cursors are arrays: one per queue segment, see trace_queue)
-struct IterCtr { uint32_t n_active, n_shadow, n_final, pad0; uint32_t w_extend[QUEUE_SEGMENTS], w_shadow[QUEUE_SEGMENTS]; };
+struct IterCtr { uint32_t n_active, n_shadow, n_final, n_walk; uint32_t w_extend[QUEUE_SEGMENTS], w_shadow[QUEUE_SEGMENTS], w_walk[QUEUE_SEGMENTS]; };
 constexpr uint32_t MAX_ITERS = 4096;
 // counter blocks past the per-iteration range [0, MAX_ITERS): one per helper, so none aliases an iteration's block or
 // another helper's
@@ -245,7 +245,11 @@ __global__ void k_raygen(SceneDev S, CameraDev cam, PathArrays P, const uint32_t
 struct ExtendSrc {
     const PathArrays& P;
     const uint32_t* q;
-    PT_DEV uint32_t key(uint32_t i) const { return q[i]; }     // the path slot
+    // the launch's queue is the iteration's active queue followed by its walk queue (subsurface step rays): one launch,
+    // one set of persistent waves, no tail between the two
+    uint32_t n_first = 0xFFFFFFFFu;
+    const uint32_t* q_second = nullptr;
+    PT_DEV uint32_t key(uint32_t i) const { return i < n_first ? q[i] : q_second[i - n_first]; }     // the path slot
     PT_DEV void fetch(uint32_t p, V3* o, V3* d, float* tmax) const {
         const float4 ro = P.ray_o[p], rd = P.ray_d[p];
         *o = v3(ro.x, ro.y, ro.z); *d = v3(rd.x, rd.y, rd.z); *tmax = ro.w;
@@ -262,14 +266,15 @@ struct ExtendSink {
     }
 };
 template <bool CNT>
-__global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
+__global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S, PathArrays P, const uint32_t* q, const uint32_t* q_walk, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
     LaneCnt lc = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nrays = 0, e = 0;
-    ExtendSrc src{P, q};
+    const uint32_t n_active = ctr->n_active, n_walk = ctr->n_walk;
+    ExtendSrc src{P, q, n_active, q_walk};
     ExtendSink sink{P};
-    trace_queue<false, CNT>(S, st, ctr->w_extend, ctr->n_active, src, sink, lc, nrays, e);
+    trace_queue<false, CNT>(S, st, ctr->w_extend, n_active + n_walk, src, sink, lc, nrays, e);
     if (e) atomicOr(err, e);
     if (CNT) flush_lane_cnt(dc, lc, nrays, false);
 }
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_extend_packet(Sc
     uint32_t e = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
-    trace_packets<false>(S, g_nodes, g_tris, g_inst_tlas, g_inst, g_tlas_prims, st, ctr->w_extend, ctr->n_active, src, sink, e, capacity,
+    trace_packets<false>(S, g_nodes, g_tris, g_inst_tlas, g_inst, g_tlas_prims, S.inst_root_faithful, S.inst_root_packet, st, ctr->w_extend, ctr->n_active, src, sink, e, capacity,
                          redo_keys, &redo_ctr->n_active, &dc->dbg[1]);
     if (e) atomicOr(err, e);
 }
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_trace_batch_pack
     uint32_t e = 0;
     BatchSrc src{rays};
     BatchSink<ANY> sink{out_hits, out_any};
-    trace_packets<ANY>(S, S.nodes, S.tris, S.inst_tlas, S.inst, S.tlas_prims, st, work, n, src, sink, e, PACKET_LDS + OVF_STACK, nullptr, nullptr, &dc->dbg[1]);
+    trace_packets<ANY>(S, S.nodes, S.tris, S.inst_tlas, S.inst, S.tlas_prims, S.inst_root_faithful, S.inst_root_packet, st, work, n, src, sink, e, PACKET_LDS + OVF_STACK, nullptr, nullptr, &dc->dbg[1]);
     if (e) atomicOr(err, e);
 }
 
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_shadow_packet(Sc
     uint32_t e = 0;
     ShadowSrc src{S, P, qs};
     ShadowSink sink{P};
-    trace_packets<true>(S, g_nodes, g_tris, g_inst_tlas, g_inst, g_tlas_prims, st, ctr->w_shadow, ctr->n_shadow, src, sink, e);
+    trace_packets<true>(S, g_nodes, g_tris, g_inst_tlas, g_inst, g_tlas_prims, S.inst_root_faithful, S.inst_root_packet, st, ctr->w_shadow, ctr->n_shadow, src, sink, e);
     if (e) atomicOr(err, e);
 }
 
@@ -375,19 +380,262 @@ PT_DEV WalkCtx walk_ctx(const PtxMaterial& m, float scale) {
     return w;
 }
 
+// head of one `for _ in 0..SSS_MAX_STEPS` iteration (subsurface.rs:78-98): pick the channel, sample the free-flight
+// distance; false = `sum_weights < 1e-10` (the walk returns None)
+PT_DEV bool walk_begin_step(const PtxMaterial& material, V3 wt, float w_scale, Rng& rng, V3 w_pos, V3 w_dir, V3* o, V3* d, float* dist) {
+    const WalkCtx wc = walk_ctx(material, w_scale);
+    const V3 weights = wt * wc.sigma_s;
+    const float sum_weights = weights.x + weights.y + weights.z;
+    if (sum_weights < 1e-10f) return false;
+    const float r = rng.next() * sum_weights;
+    const int channel = (r < weights.x) ? 0 : ((r < weights.x + weights.y) ? 1 : 2);
+    const float sigma_t_c = comp(wc.sigma_t, channel);
+    *dist = -d_logf(f_max(rng.next(), 1e-10f)) / sigma_t_c;
+    *o = w_pos; *d = w_dir;
+    return true;
+}
+
+// ---- the subsurface states of trace_inner (pathtracer.rs:203-271, subsurface.rs:58-160) ---------------------------
+// A path that refracts into a subsurface medium leaves k_shade for the WALK QUEUE and stays there until the event is
+// over; its rays (thickness ray, then one step ray per walk step, t_max = the sampled distance) are traced by k_extend
+// together with the active queue, and this kernel does one state transition per iteration for every path on the queue:
+//   ST_THICK  thickness ray traced -> thickness scale, head of the first walk step
+//   ST_WALK   step ray traced -> leave through an exiting surface / hop through an entering one / scatter, then the
+//             head of the next step.  At an exiting surface the event ends here as well: exit tint, Russian roulette,
+//             sun and sky light sampling at the exit point (shadow rays go to this iteration's shadow queue), cosine
+//             bounce — and the path returns to the next iteration's ACTIVE queue in state ST_NORMAL.
+// A walk that returns None retires the path.  The integrator kernel never sees a subsurface state, so it carries none of
+// this code or its registers, and the walk code runs on full waves instead of on the few walk lanes of a mixed wave.
+#ifndef PT_WALK_BLOCK
+#define PT_WALK_BLOCK 256
+#endif
+constexpr int WALK_BLOCK = PT_WALK_BLOCK;
+template <bool CNT>
+__global__ __launch_bounds__(WALK_BLOCK) void k_sss_step(SceneDev S, PathArrays P, const uint32_t* q_walk, uint32_t* q_walk_next, uint32_t* q_next,
+                                                         uint32_t* q_shadow, uint32_t* q_final, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
+                                                         DevCounters* dc) {
+    __shared__ uint32_t s_cnt[4][WALK_BLOCK / 64];
+    __shared__ uint32_t s_base[4];
+    const uint32_t n = ctr->n_walk;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        const bool active = i < n;
+        bool alive = false, exited = false, push_sun = false, push_sky = false;
+        uint32_t p = 0;
+        if (active) {
+            p = q_walk[i];
+            const float4 ro4 = P.ray_o[p], rd4 = P.ray_d[p], wb4 = P.w_b[p], hi4 = P.hit[p];
+            const uint2 rs = P.rng[p];
+            Rng rng;
+            rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+            uint32_t* flags_word = reinterpret_cast<uint32_t*>(&P.thr[p]) + 3;
+            uint32_t flags = *flags_word;
+            uint32_t step = (flags & FL_STEP_MASK) >> FL_STEP_SHIFT;
+            const uint32_t state = (flags & FL_STATE_MASK) >> FL_STATE_SHIFT;
+            V3 w_pos = v3(ro4.x, ro4.y, ro4.z), w_dir = v3(rd4.x, rd4.y, rd4.z);
+            const float dist = ro4.w;
+            float last_pdf = rd4.w;
+            const bool has_hit = __float_as_uint(hi4.w) != PTX_MISS;
+            const PtxMaterial& material = S.materials[__float_as_uint(wb4.w)];
+            V3 wt = splat(1.0f);
+            float w_scale = 1.0f;
+            alive = true;
+            V3 exit_point = splat(0.0f), exit_n = splat(0.0f);
+            if (state == ST_THICK) {
+                // thickness ray (pathtracer.rs:207-219): the walk starts at the entry point along the entry direction
+                float thickness = 1.0f;
+                if (has_hit) {
+                    const HitData bh = compute_hit_data(S, __float_as_uint(hi4.w), P.hit_tri[p], hi4.x, hi4.y, hi4.z);
+                    if (CNT) sc.hitdata++;
+                    if (dot(w_dir, bh.normal) > 0.0f) thickness = bh.t;
+                }
+                w_scale = f_clamp(thickness / 1.0f, 0.1f, 2.0f);
+                step = 0;
+            } else {
+                const float4 wt4 = P.w_t[p];
+                wt = v3(wt4.x, wt4.y, wt4.z);
+                w_scale = wt4.w;
+                const WalkCtx wc = walk_ctx(material, w_scale);
+                const V3 weights = wt * wc.sigma_s;
+                const float sum_weights = weights.x + weights.y + weights.z;
+                if (has_hit) {
+                    const HitData wh = compute_hit_data(S, __float_as_uint(hi4.w), P.hit_tri[p], hi4.x, hi4.y, hi4.z);
+                    if (CNT) sc.hitdata++;
+                    const V3 hit_point = w_pos + w_dir * wh.t;
+                    if (dot(w_dir, wh.normal) > 0.0f) {
+                        // exiting surface (subsurface.rs:104-117)
+                        const float t = wh.t;
+                        const V3 tr = v3(d_expf(-wc.sigma_t.x * t), d_expf(-wc.sigma_t.y * t), d_expf(-wc.sigma_t.z * t));
+                        const float pdf_sum = (tr.x * (weights.x / sum_weights) + tr.y * (weights.y / sum_weights)) + tr.z * (weights.z / sum_weights);
+                        wt = wt * (tr / f_max(pdf_sum, 1e-10f));
+                        exit_point = hit_point; exit_n = wh.normal;
+                        exited = true;
+                    } else {
+                        w_pos = hit_point + w_dir * RAY_EPSILON;       // entering surface: hop over it, the step is spent
+                    }
+                } else {
+                    // no surface within the sampled distance: scatter there (subsurface.rs:125-157)
+                    w_pos = w_pos + w_dir * dist;
+                    const V3 tr = v3(d_expf(-wc.sigma_t.x * dist), d_expf(-wc.sigma_t.y * dist), d_expf(-wc.sigma_t.z * dist));
+                    const float pdf_sum = (wc.sigma_t.x * tr.x * (weights.x / sum_weights) + wc.sigma_t.y * tr.y * (weights.y / sum_weights)) +
+                                          wc.sigma_t.z * tr.z * (weights.z / sum_weights);
+                    wt = wt * (tr * wc.sigma_s / f_max(pdf_sum, 1e-10f));
+                    const float max_tp = max_element(wt);
+                    if (max_tp < 0.1f) {
+                        const float survive = f_min(max_tp * 10.0f, 1.0f);
+                        if (rng.next() > survive) alive = false;
+                        else wt = wt / survive;
+                    }
+                    if (alive && (!is_finite(wt) || max_tp > 1000.0f)) alive = false;
+                    if (alive) {
+                        // sample_hg_phase (subsurface.rs:41-56)
+                        const float g = material.subsurface_anisotropy;
+                        float cos_theta;
+                        if (fabsf(g) < 0.001f) cos_theta = 1.0f - 2.0f * rng.next();
+                        else {
+                            const float g2 = g * g;
+                            const float sqr = (1.0f - g2) / (1.0f - g + 2.0f * g * rng.next());
+                            cos_theta = f_clamp((1.0f + g2 - sqr * sqr) / (2.0f * g), -1.0f, 1.0f);
+                        }
+                        const float sin_theta = sqrtf(f_max(1.0f - cos_theta * cos_theta, 0.0f));
+                        const float phi = 2.0f * PT_PI * rng.next();
+                        const V3 nn = -w_dir;
+                        V3 tb, bb;
+                        build_basis(nn, &tb, &bb);
+                        float sp, cp;
+                        d_sincosf(phi, &sp, &cp);
+                        w_dir = to_world(v3(sin_theta * cp, sin_theta * sp, cos_theta), tb, bb, nn);
+                    }
+                }
+            }
+            if (alive && !exited) {
+                // head of the next `for _ in 0..SSS_MAX_STEPS` iteration (subsurface.rs:78-98)
+                float next_dist = 0.0f;
+                if (step >= 64u) alive = false;
+                else {
+                    if (CNT) sc.sss_steps++;
+                    V3 so, sd;
+                    if (!walk_begin_step(material, wt, w_scale, rng, w_pos, w_dir, &so, &sd, &next_dist)) alive = false;
+                    else step++;
+                }
+                if (alive) {
+                    flags = (flags & ~(FL_STEP_MASK | FL_STATE_MASK)) | ((step << FL_STEP_SHIFT) & FL_STEP_MASK) | (ST_WALK << FL_STATE_SHIFT);
+                    *flags_word = flags;
+                    P.w_t[p] = make_float4(wt.x, wt.y, wt.z, w_scale);
+                    P.rng[p] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                    P.ray_o[p] = make_float4(w_pos.x, w_pos.y, w_pos.z, next_dist);
+                    P.ray_d[p] = make_float4(w_dir.x, w_dir.y, w_dir.z, last_pdf);
+                }
+            }
+            if (exited) {
+                // success branch of trace_inner (pathtracer.rs:230-271)
+                const float4 th4 = P.thr[p];
+                V3 T = v3(th4.x, th4.y, th4.z);
+                uint32_t bounce = flags & FL_BOUNCE_MASK;
+                const V3 sss_base = v3(wb4.x, wb4.y, wb4.z);
+                const V3 sun_dir = v3(S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]);
+                const V3 sun_color = v3(S.sun_color[0], S.sun_color[1], S.sun_color[2]);
+                T = T * (sss_base * wt * v3(material.subsurface_exit_tint[0], material.subsurface_exit_tint[1], material.subsurface_exit_tint[2]));
+                if (!russian_roulette(rng, T, bounce)) alive = false;
+                else {
+                    const V3 diffuse_brdf = sss_base / PT_PI;
+                    const V3 sh_o = exit_point + exit_n * RAY_EPSILON;
+                    P.sh_o[p] = make_float4(sh_o.x, sh_o.y, sh_o.z, 0.0f);
+                    if (S.sun_enabled) {
+                        const float n_dot_l = dot(exit_n, sun_dir);
+                        if (n_dot_l > 0.0f) { const V3 c_sun = T * diffuse_brdf * sun_color * n_dot_l; push_sun = true; P.c_sun[p] = make_float4(c_sun.x, c_sun.y, c_sun.z, 0.0f); }
+                    }
+                    {
+                        const float u1 = rng.next();
+                        const float u2 = rng.next();
+                        const SkySample ss = sky_sample_direction<!CNT>(S, u1, u2, sc);
+                        const float n_dot_l = dot(exit_n, ss.direction);
+                        if (n_dot_l > 0.0f && ss.pdf > 0.0f) {
+                            const V3 sky_contribution = clamp_radiance(ss.radiance * safe_inv_pdf(ss.pdf));
+                            const V3 c_sky = T * diffuse_brdf * sky_contribution * n_dot_l;
+                            push_sky = true;
+                            P.c_sky[p] = make_float4(c_sky.x, c_sky.y, c_sky.z, 0.0f);
+                            P.sh_d[p] = make_float4(ss.direction.x, ss.direction.y, ss.direction.z, 0.0f);
+                        }
+                    }
+                    V3 et, eb;
+                    build_basis(exit_n, &et, &eb);
+                    const float u1 = rng.next();
+                    const float u2 = rng.next();
+                    const V3 exit_dir = to_world(sample_cosine_hemisphere(u1, u2), et, eb, exit_n);
+                    const V3 ro = exit_point + exit_n * RAY_EPSILON;
+                    last_pdf = pdf_cosine(f_max(dot(exit_n, exit_dir), 0.001f));
+                    bounce++;
+                    // `for bounce in 0..MAX_BOUNCES` ran out (pathtracer.rs:117)
+                    if (bounce >= max_bounces) alive = false;
+                    // back to the integrator: ST_NORMAL, not specular, step count cleared; FL_FIRST_HIT is long gone
+                    flags = bounce & FL_BOUNCE_MASK;
+                    P.ray_o[p] = make_float4(ro.x, ro.y, ro.z, PT_INF);
+                    P.ray_d[p] = make_float4(exit_dir.x, exit_dir.y, exit_dir.z, last_pdf);
+                    P.thr[p] = make_float4(T.x, T.y, T.z, __uint_as_float(flags));
+                    P.rng[p] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                    // the NEE terms wait behind their shadow rays: flag them for the next k_shade / k_finalize
+                    uint32_t* pix = reinterpret_cast<uint32_t*>(&P.rad[p]) + 3;
+                    *pix = (*pix & PIXEL_MASK) | (push_sun ? PEND_SUN : 0u) | (push_sky ? PEND_SKY : 0u);
+                }
+            }
+        }
+        // four queues, block totals through LDS, one atomic per queue and block iteration (as in k_shade)
+        {
+            const uint32_t wave = threadIdx.x >> 6;
+            const unsigned long long m_sun = __ballot(active && push_sun), m_sky = __ballot(active && push_sky);
+            const unsigned long long m_walk = __ballot(active && alive && !exited), m_exit = __ballot(active && alive && exited);
+            const unsigned long long m_fin = __ballot(active && !alive);
+            const uint32_t n_sun = (uint32_t)__popcll(m_sun), n_sky = (uint32_t)__popcll(m_sky);
+            if ((threadIdx.x & 63u) == 0u) {
+                s_cnt[0][wave] = n_sun + n_sky;
+                s_cnt[1][wave] = (uint32_t)__popcll(m_exit);
+                s_cnt[2][wave] = (uint32_t)__popcll(m_fin);
+                s_cnt[3][wave] = (uint32_t)__popcll(m_walk);
+            }
+            __syncthreads();
+            if (threadIdx.x < 4u) {
+                uint32_t total = 0;
+                for (uint32_t k = 0; k < WALK_BLOCK / 64; ++k) total += s_cnt[threadIdx.x][k];
+                uint32_t* counter = threadIdx.x == 0u ? &ctr->n_shadow : (threadIdx.x == 1u ? &ctr_next->n_active : (threadIdx.x == 2u ? &ctr->n_final : &ctr_next->n_walk));
+                s_base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
+            }
+            __syncthreads();
+            uint32_t o_sh = s_base[0], o_ex = s_base[1], o_fi = s_base[2], o_wk = s_base[3];
+            for (uint32_t k = 0; k < wave; ++k) { o_sh += s_cnt[0][k]; o_ex += s_cnt[1][k]; o_fi += s_cnt[2][k]; o_wk += s_cnt[3][k]; }
+            if (active && push_sun) q_shadow[o_sh + wave_rank(m_sun)] = p * 2u;
+            if (active && push_sky) q_shadow[o_sh + n_sun + wave_rank(m_sky)] = p * 2u + 1u;
+            if (active && alive && !exited) q_walk_next[o_wk + wave_rank(m_walk)] = p;
+            if (active && alive && exited) q_next[o_ex + wave_rank(m_exit)] = p;
+            if (active && !alive) q_final[o_fi + wave_rank(m_fin)] = p;      // walk returned None, roulette, or out of bounces
+            __syncthreads();
+        }
+    }
+    if (CNT) {
+        wave_add(&dc->v[C_HITDATA], sc.hitdata);
+        wave_add(&dc->v[C_SSS_STEPS], sc.sss_steps);
+        wave_add(&dc->v[C_CDF_PROBES], sc.cdf_probes);
+        wave_add(&dc->v[C_SKY_PDF], sc.sky_pdf);
+        wave_add(&dc->v[C_SKY_TEXEL], sc.sky_texel);
+        wave_add(&dc->v[C_TEXTURE], sc.texture);
+    }
+}
+
 template <bool CNT>
 __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S, PathArrays P, const uint32_t* q, uint32_t* q_next, uint32_t* q_shadow,
-                                                       uint32_t* q_final, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
+                                                       uint32_t* q_final, uint32_t* q_walk, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
                                                        DevCounters* dc) {
-    __shared__ uint32_t s_cnt[3][SHADE_BLOCK / 64];
-    __shared__ uint32_t s_base[3];
+    __shared__ uint32_t s_cnt[4][SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base[4];
     const uint32_t n = ctr->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
     ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
-        bool alive = false, push_sun = false, push_sky = false;
+        bool alive = false, push_sun = false, push_sky = false, walk = false;
         uint32_t p = 0;
         if (active) {
             p = q[i];
@@ -421,12 +669,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
             const V3 sun_dir = v3(S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]);
             const V3 sun_color = v3(S.sun_color[0], S.sun_color[1], S.sun_color[2]);
 
-            bool begin_walk_step = false, sss_exit = false;
-            V3 w_pos = ro, w_dir = rd, wt = splat(1.0f), exit_point = splat(0.0f), exit_n = splat(0.0f), sss_base = splat(0.0f);
-            float w_scale = 1.0f;
-            uint32_t w_mat = 0;
-
-            if (state == ST_NORMAL) {
+            {
                 if (!has_hit) {
                     // miss (pathtracer.rs:118-134)
                     const V3 sky_radiance = sky_sample(S, rd, sc);
@@ -612,149 +855,12 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                         }
                     }
                 }
-            } else {
-                // ---- subsurface states (pathtracer.rs:207-229, subsurface.rs:58-160)
-                const float4 wb4 = P.w_b[p];
-                sss_base = v3(wb4.x, wb4.y, wb4.z);
-                w_mat = __float_as_uint(wb4.w);
-                const PtxMaterial& material = S.materials[w_mat];
-                if (state == ST_THICK) {
-                    float thickness = 1.0f;
-                    if (has_hit) {
-                        const HitData bh = compute_hit_data(S, h_inst, P.hit_tri[p], hi4.x, hi4.y, hi4.z);
-                        if (CNT) sc.hitdata++;
-                        if (dot(rd, bh.normal) > 0.0f) thickness = bh.t;
-                    }
-                    w_scale = f_clamp(thickness / 1.0f, 0.1f, 2.0f);
-                    wt = splat(1.0f);
-                    step = 0;
-                    begin_walk_step = true;
-                } else {
-                    const float4 wt4 = P.w_t[p];
-                    wt = v3(wt4.x, wt4.y, wt4.z);
-                    w_scale = wt4.w;
-                    const WalkCtx wc = walk_ctx(material, w_scale);
-                    const V3 weights = wt * wc.sigma_s;
-                    const float sum_weights = weights.x + weights.y + weights.z;
-                    const float dist = ray_tmax;
-                    bool walk_done = false;
-                    if (has_hit) {
-                        const HitData wh = compute_hit_data(S, h_inst, P.hit_tri[p], hi4.x, hi4.y, hi4.z);
-                        if (CNT) sc.hitdata++;
-                        const V3 hit_point = w_pos + w_dir * wh.t;
-                        if (dot(w_dir, wh.normal) > 0.0f) {
-                            const float t = wh.t;
-                            const V3 tr = v3(d_expf(-wc.sigma_t.x * t), d_expf(-wc.sigma_t.y * t), d_expf(-wc.sigma_t.z * t));
-                            const float pdf_sum = (tr.x * (weights.x / sum_weights) + tr.y * (weights.y / sum_weights)) + tr.z * (weights.z / sum_weights);
-                            wt = wt * (tr / f_max(pdf_sum, 1e-10f));
-                            exit_point = hit_point; exit_n = wh.normal;
-                            sss_exit = true;
-                        } else {
-                            w_pos = hit_point + w_dir * RAY_EPSILON;
-                            begin_walk_step = true;
-                        }
-                        walk_done = true;
-                    }
-                    if (!walk_done) {
-                        w_pos = w_pos + w_dir * dist;
-                        const V3 tr = v3(d_expf(-wc.sigma_t.x * dist), d_expf(-wc.sigma_t.y * dist), d_expf(-wc.sigma_t.z * dist));
-                        const float pdf_sum = (wc.sigma_t.x * tr.x * (weights.x / sum_weights) + wc.sigma_t.y * tr.y * (weights.y / sum_weights)) +
-                                              wc.sigma_t.z * tr.z * (weights.z / sum_weights);
-                        wt = wt * (tr * wc.sigma_s / f_max(pdf_sum, 1e-10f));
-                        const float max_tp = max_element(wt);
-                        bool dead = false;
-                        if (max_tp < 0.1f) {
-                            const float survive = f_min(max_tp * 10.0f, 1.0f);
-                            if (rng.next() > survive) dead = true;
-                            else wt = wt / survive;
-                        }
-                        if (!dead && (!is_finite(wt) || max_tp > 1000.0f)) dead = true;
-                        if (dead) alive = false;   // random_walk_subsurface -> None -> break
-                        else {
-                            // sample_hg_phase (subsurface.rs:41-56)
-                            const float g = material.subsurface_anisotropy;
-                            float cos_theta;
-                            if (fabsf(g) < 0.001f) cos_theta = 1.0f - 2.0f * rng.next();
-                            else {
-                                const float g2 = g * g;
-                                const float sqr = (1.0f - g2) / (1.0f - g + 2.0f * g * rng.next());
-                                cos_theta = f_clamp((1.0f + g2 - sqr * sqr) / (2.0f * g), -1.0f, 1.0f);
-                            }
-                            const float sin_theta = sqrtf(f_max(1.0f - cos_theta * cos_theta, 0.0f));
-                            const float phi = 2.0f * PT_PI * rng.next();
-                            const V3 nn = -w_dir;
-                            V3 tb, bb;
-                            build_basis(nn, &tb, &bb);
-                            float sp, cp;
-                            d_sincosf(phi, &sp, &cp);
-                            w_dir = to_world(v3(sin_theta * cp, sin_theta * sp, cos_theta), tb, bb, nn);
-                            begin_walk_step = true;
-                        }
-                    }
-                }
-                if (begin_walk_step) {
-                    // head of one `for _ in 0..SSS_MAX_STEPS` iteration (subsurface.rs:78-98)
-                    if (step >= 64u) alive = false;
-                    else {
-                        if (CNT) sc.sss_steps++;
-                        const WalkCtx wc = walk_ctx(material, w_scale);
-                        const V3 weights = wt * wc.sigma_s;
-                        const float sum_weights = weights.x + weights.y + weights.z;
-                        if (sum_weights < 1e-10f) alive = false;
-                        else {
-                            const float r = rng.next() * sum_weights;
-                            const int channel = (r < weights.x) ? 0 : ((r < weights.x + weights.y) ? 1 : 2);
-                            const float sigma_t_c = comp(wc.sigma_t, channel);
-                            const float dist = -d_logf(f_max(rng.next(), 1e-10f)) / sigma_t_c;
-                            ro = w_pos; rd = w_dir; ray_tmax = dist;
-                            state = ST_WALK;
-                            step++;
-                            P.w_t[p] = make_float4(wt.x, wt.y, wt.z, w_scale);
-                        }
-                    }
-                }
-                if (sss_exit) {
-                    // success branch of trace_inner (pathtracer.rs:230-271)
-                    T = T * (sss_base * wt * v3(material.subsurface_exit_tint[0], material.subsurface_exit_tint[1], material.subsurface_exit_tint[2]));
-                    if (!russian_roulette(rng, T, bounce)) alive = false;
-                    else {
-                        const V3 diffuse_brdf = sss_base / PT_PI;
-                        sh_o = exit_point + exit_n * RAY_EPSILON;
-                        P.sh_o[p] = make_float4(sh_o.x, sh_o.y, sh_o.z, 0.0f);
-                        if (S.sun_enabled) {
-                            const float n_dot_l = dot(exit_n, sun_dir);
-                            if (n_dot_l > 0.0f) { c_sun = T * diffuse_brdf * sun_color * n_dot_l; push_sun = true; P.c_sun[p] = make_float4(c_sun.x, c_sun.y, c_sun.z, 0.0f); }
-                        }
-                        {
-                            const float u1 = rng.next();
-                            const float u2 = rng.next();
-                            const SkySample ss = sky_sample_direction<!CNT>(S, u1, u2, sc);
-                            const float n_dot_l = dot(exit_n, ss.direction);
-                            if (n_dot_l > 0.0f && ss.pdf > 0.0f) {
-                                const V3 sky_contribution = clamp_radiance(ss.radiance * safe_inv_pdf(ss.pdf));
-                                c_sky = T * diffuse_brdf * sky_contribution * n_dot_l;
-                                sh_d = ss.direction;
-                                push_sky = true;
-                                P.c_sky[p] = make_float4(c_sky.x, c_sky.y, c_sky.z, 0.0f);
-                                P.sh_d[p] = make_float4(sh_d.x, sh_d.y, sh_d.z, 0.0f);
-                            }
-                        }
-                        V3 et, eb;
-                        build_basis(exit_n, &et, &eb);
-                        const float u1 = rng.next();
-                        const float u2 = rng.next();
-                        const V3 exit_dir = to_world(sample_cosine_hemisphere(u1, u2), et, eb, exit_n);
-                        ro = exit_point + exit_n * RAY_EPSILON; rd = exit_dir; ray_tmax = PT_INF;
-                        last_spec = false;
-                        last_pdf = pdf_cosine(f_max(dot(exit_n, exit_dir), 0.001f));
-                        state = ST_NORMAL;
-                        bounce++;
-                    }
-                }
             }
+            // (paths in a subsurface state never come here: they live on the walk queue, k_sss_step)
 
             // `for bounce in 0..MAX_BOUNCES` ran out (pathtracer.rs:117)
             if (alive && state == ST_NORMAL && bounce >= max_bounces) alive = false;
+            walk = alive && state == ST_THICK;       // refracted into a subsurface medium: the thickness ray is traced with the walk queue
 
             flags = (bounce & FL_BOUNCE_MASK) | (last_spec ? FL_SPECULAR : 0u) | (state << FL_STATE_SHIFT) |
                     (first_hit ? FL_FIRST_HIT : 0u) | ((step << FL_STEP_SHIFT) & FL_STEP_MASK);
@@ -775,29 +881,32 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
         {
             const uint32_t wave = threadIdx.x >> 6;
             const unsigned long long m_sun = __ballot(active && push_sun), m_sky = __ballot(active && push_sky);
-            const unsigned long long m_next = __ballot(active && alive), m_fin = __ballot(active && !alive);
+            // a path that starts a subsurface walk goes to the next iteration's walk queue (k_walk_step takes it from there
+            // until the walk ends), every other live path to the next iteration's active queue
+            const unsigned long long m_next = __ballot(active && alive && !walk), m_fin = __ballot(active && !alive);
+            const unsigned long long m_walk = __ballot(active && walk);
             const uint32_t n_sun = (uint32_t)__popcll(m_sun), n_sky = (uint32_t)__popcll(m_sky);
             if ((threadIdx.x & 63u) == 0u) {
                 s_cnt[0][wave] = n_sun + n_sky;
                 s_cnt[1][wave] = (uint32_t)__popcll(m_next);
                 s_cnt[2][wave] = (uint32_t)__popcll(m_fin);
+                s_cnt[3][wave] = (uint32_t)__popcll(m_walk);
             }
             __syncthreads();
-            if (threadIdx.x < 3u) {
+            if (threadIdx.x < 4u) {
                 uint32_t total = 0;
                 for (uint32_t k = 0; k < SHADE_BLOCK / 64; ++k) total += s_cnt[threadIdx.x][k];
-                uint32_t* counter = threadIdx.x == 0u ? &ctr->n_shadow : (threadIdx.x == 1u ? &ctr_next->n_active : &ctr->n_final);
+                uint32_t* counter = threadIdx.x == 0u ? &ctr->n_shadow : (threadIdx.x == 1u ? &ctr_next->n_active : (threadIdx.x == 2u ? &ctr->n_final : &ctr_next->n_walk));
                 s_base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
             }
             __syncthreads();
-            uint32_t o_sh = s_base[0], o_nx = s_base[1], o_fi = s_base[2];
-            for (uint32_t k = 0; k < wave; ++k) { o_sh += s_cnt[0][k]; o_nx += s_cnt[1][k]; o_fi += s_cnt[2][k]; }
-            const uint32_t lane_lo = threadIdx.x & 63u;
-            (void)lane_lo;
+            uint32_t o_sh = s_base[0], o_nx = s_base[1], o_fi = s_base[2], o_wk = s_base[3];
+            for (uint32_t k = 0; k < wave; ++k) { o_sh += s_cnt[0][k]; o_nx += s_cnt[1][k]; o_fi += s_cnt[2][k]; o_wk += s_cnt[3][k]; }
             if (active && push_sun) q_shadow[o_sh + wave_rank(m_sun)] = p * 2u;
             if (active && push_sky) q_shadow[o_sh + n_sun + wave_rank(m_sky)] = p * 2u + 1u;
-            if (active && alive) q_next[o_nx + wave_rank(m_next)] = p;
+            if (active && alive && !walk) q_next[o_nx + wave_rank(m_next)] = p;
             if (active && !alive) q_final[o_fi + wave_rank(m_fin)] = p;
+            if (active && walk) q_walk[o_wk + wave_rank(m_walk)] = p;
             __syncthreads();   // s_cnt / s_base are rewritten by the next iteration
         }
     }
@@ -1130,7 +1239,7 @@ struct PtxContext {
     uint64_t capacity = 0;
     PathArrays P{};
     std::vector<void*> path_allocs;
-    uint32_t *q[2] = {nullptr, nullptr}, *q_shadow = nullptr, *q_final = nullptr, *q_redo = nullptr;
+    uint32_t *q[2] = {nullptr, nullptr}, *q_shadow = nullptr, *q_final = nullptr, *q_redo = nullptr, *q_walk[2] = {nullptr, nullptr};
     int packet_capacity = PACKET_LDS + OVF_STACK;   // PTX_PACKET_CAPACITY (tests): smaller packet stacks, to exercise the redo path
     IterCtr* ctrs = nullptr;
     uint2* ovf = nullptr;
@@ -1152,6 +1261,10 @@ struct PtxContext {
     float *fb_sum = nullptr, *fb_sum_sq = nullptr; uint32_t* fb_counts = nullptr;
 
     bool packet_primary = true, packet_shadow = false, packet_batch = false;   // PTX_PACKET_SHADOW=1: the first shadow launch as packets too (measured: 132 -> 137 ms, its queue interleaves sun and sky rays)   // PTX_PACKET_PRIMARY (0 disables), PTX_PACKET_BATCH (tests: ptx_trace_batch through the packet kernel)
+    // children per record of the collapsed trees (0 / 1 = walk the faithful tree): the packet kernels gain from wide records
+    // (one record fetch serves 64 rays: primary launch 66 -> 60 ms at 8), the per-ray kernels lose (they are VALU-issue
+    // bound and a wider record means more box tests per ray: extend 368 -> 402 ms at 4, 550 ms at 8 with 5 waves/SIMD)
+    uint32_t packet_width = 8, ray_width = 0;     // PTX_WIDE_BVH, PTX_WIDE_RAY_BVH
     uint32_t adaptive_batch = 32;   // adaptive passes traced together by ptx_fb_adaptive_passes (PTX_ADAPTIVE_BATCH)
     bool counting = false, profiling = false;
     struct Ev { hipEvent_t a, b; int cls; };
@@ -1212,67 +1325,151 @@ static void free_pool(std::vector<void*>& pool) {
     pool.clear();
 }
 
-// ---- Bvh8Node[] (256 B, 8 slots) -> NodeRec[] (128 B, <= 4 children; wider nodes become a chain) ----
-// Returns false on an out-of-range child word or an empty node.  *root_word = record 0 with its child count.
-static bool repack_bvh(const PtxBvh8& bvh, std::vector<NodeRec>& out, uint32_t* n_records, uint32_t* root_word) {
+// ---- Bvh8Node[] (256 B, 8 slots) -> NodeRec units: the faithful tree and its order-preserving wide collapse ----
+// (layout and the argument why the collapse cannot change a result: pt_types.h)
+struct RepackItem { float box[6]; uint32_t word; };   // min.xyz, max.xyz; word = the reference child word (internal: node index)
+
+// a node's children in the order the reference's walk takes them: leaf slots ascending, then internal slots descending
+static void ordered_children(const PtxBvh8Node& nd, std::vector<RepackItem>& out) {
+    out.clear();
+    auto item = [&nd](int s) {
+        RepackItem it;
+        it.box[0] = nd.min_x[s]; it.box[1] = nd.min_y[s]; it.box[2] = nd.min_z[s];
+        it.box[3] = nd.max_x[s]; it.box[4] = nd.max_y[s]; it.box[5] = nd.max_z[s];
+        it.word = nd.children[s];
+        return it;
+    };
+    for (int s = 0; s < 8; ++s) if ((nd.valid_mask & (1u << s)) && (nd.children[s] & LEAF_FLAG)) out.push_back(item(s));
+    for (int s = 7; s >= 0; --s) if ((nd.valid_mask & (1u << s)) && !(nd.children[s] & LEAF_FLAG)) out.push_back(item(s));
+}
+static void fill_record(NodeRec* rec, const std::vector<RepackItem>& list, const std::vector<uint32_t>& words, uint32_t meta) {
+    auto as_f = [](uint32_t w) { float f; std::memcpy(&f, &w, 4); return f; };
+    const size_t units = list.size() > 4 ? 2 : 1;
+    std::memset(rec, 0, sizeof(NodeRec) * units);
+    for (size_t k = 0; k < list.size(); ++k) {
+        NodeRec& r = rec[k / 4];
+        const float* b = list[k].box;
+        r.c[2 * (k % 4)] = make_float4(b[0], b[1], b[2], b[3]);
+        r.c[2 * (k % 4) + 1] = make_float4(b[4], b[5], as_f(words[k]), 0.0f);
+    }
+    rec[0].c[1].w = as_f(meta);
+}
+constexpr uint32_t REPACK_MAX_DEPTH = 512;
+// Returns false on an out-of-range child word, an empty node, or a node graph that is not a tree.
+// *root_faithful / *root_ray / *root_packet = root child words (absolute unit index | (children - 1) << 28) of the faithful tree and
+// of the collapsed trees the per-ray and the packet kernels walk (width <= 1: no collapse, the faithful root).
+static bool repack_wide(const PtxBvh8& bvh, const std::vector<uint32_t>& count, std::vector<NodeRec>& out, uint32_t width, uint32_t* root_wide);
+static bool repack_bvh(const PtxBvh8& bvh, std::vector<NodeRec>& out, uint32_t* root_faithful, uint32_t ray_width, uint32_t* root_ray,
+                       uint32_t packet_width, uint32_t* root_packet) {
     const size_t first = out.size();
     const uint32_t n = bvh.n_nodes;
-    if (n == 0 || n > NODE_INDEX_MASK / 3) return false;
-    std::vector<uint32_t> rec_index(n), first_count(n);
-    uint32_t total = 0;
+    if (n == 0 || n > NODE_INDEX_MASK / 2) return false;
+    std::vector<uint32_t> unit(n), count(n);
+    uint64_t total = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const int nv = __builtin_popcount(bvh.nodes[i].valid_mask);
         if (nv == 0) return false;
-        rec_index[i] = total;
-        total += nv <= 4 ? 1u : (nv <= 7 ? 2u : 3u);
-        first_count[i] = nv <= 4 ? (uint32_t)nv : 4u;
-    }
-    auto as_f = [](uint32_t w) { float f; std::memcpy(&f, &w, 4); return f; };
-    if (first + (size_t)total > NODE_INDEX_MASK) return false;
-    const uint32_t abs0 = (uint32_t)first;   // child words carry absolute record indices
-    auto internal_word = [abs0](uint32_t rec, uint32_t count) { return (abs0 + rec) | ((count - 1u) << NODE_NCHILD_SHIFT); };
-    out.resize(first + total);
-    const float inf = __builtin_inff();
-    for (uint32_t i = 0; i < n; ++i) {
-        const PtxBvh8Node& nd = bvh.nodes[i];
-        int slots[8], ns = 0;
-        for (int s = 0; s < 8; ++s) if (nd.valid_mask & (1u << s)) slots[ns++] = s;
-        int done = 0;
-        uint32_t rec = rec_index[i];
-        bool head = true;
-        while (done < ns) {
-            NodeRec& r = out[first + rec];
-            std::memset(&r, 0, sizeof(r));
-            const int left = ns - done;
-            const int real = left <= 4 ? left : 3;            // children of the reference node in this record
-            for (int k = 0; k < real; ++k) {
-                const int s = slots[done + k];
-                uint32_t word = nd.children[s];
-                if (word & LEAF_FLAG) {
-                    const uint32_t start = word & PRIM_START_MASK, count = ((word >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
-                    if ((uint64_t)start + count > bvh.n_primitive_indices) return false;
-                } else {
-                    if (word >= n) return false;
-                    word = internal_word(rec_index[word], first_count[word]);
-                }
-                r.c[2 * k] = make_float4(nd.min_x[s], nd.min_y[s], nd.min_z[s], nd.max_x[s]);
-                r.c[2 * k + 1] = make_float4(nd.max_y[s], nd.max_z[s], as_f(word), 0.0f);
-            }
-            if (left > 4) {
-                // pseudo child: the rest of the node, unbounded box (t_enter = t_min, always "hit"), placed last
-                const int rest = left - 3;
-                const uint32_t next_count = rest <= 4 ? (uint32_t)rest : 4u;
-                r.c[6] = make_float4(-inf, -inf, -inf, inf);
-                r.c[7] = make_float4(inf, inf, as_f(internal_word(rec + 1u, next_count)), 0.0f);
-            }
-            r.c[1].w = as_f(head ? ((uint32_t)ns | 16u) : 0u);
-            head = false;
-            done += real;
-            rec += 1u;
+        unit[i] = (uint32_t)total;
+        count[i] = (uint32_t)nv;
+        total += nv <= 4 ? 1u : 2u;
+        for (int s = 0; s < 8; ++s) {
+            if (!(bvh.nodes[i].valid_mask & (1u << s))) continue;
+            const uint32_t word = bvh.nodes[i].children[s];
+            if (word & LEAF_FLAG) {
+                const uint32_t start = word & PRIM_START_MASK, cnt = ((word >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
+                if ((uint64_t)start + cnt > bvh.n_primitive_indices) return false;
+            } else if (word >= n) return false;
         }
     }
-    *n_records = total;
-    *root_word = internal_word(0u, first_count[0]);
+    if (first + 2 * total > NODE_INDEX_MASK) return false;
+    const uint32_t abs0 = (uint32_t)first;   // child words carry absolute unit indices
+    auto internal_word = [](uint32_t abs_unit, uint32_t cnt) { return abs_unit | ((cnt - 1u) << NODE_NCHILD_SHIFT); };
+    // ---- faithful tree: one record per reference node
+    out.resize(first + total);
+    std::vector<RepackItem> list;
+    std::vector<uint32_t> words;
+    for (uint32_t i = 0; i < n; ++i) {
+        ordered_children(bvh.nodes[i], list);
+        words.resize(list.size());
+        for (size_t k = 0; k < list.size(); ++k)
+            words[k] = (list[k].word & LEAF_FLAG) ? list[k].word : internal_word(abs0 + unit[list[k].word], count[list[k].word]);
+        fill_record(&out[first + unit[i]], list, words, count[i] | 16u);
+    }
+    *root_faithful = internal_word(abs0 + unit[0], count[0]);
+    *root_ray = *root_packet = *root_faithful;
+    // ---- the walk from the root must be a tree (a cycle would never end on the GPU either)
+    {
+        std::vector<uint8_t> seen(n, 0);
+        std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 0u}};
+        seen[0] = 1;
+        while (!stack.empty()) {
+            const auto [i, depth] = stack.back();
+            stack.pop_back();
+            if (depth > REPACK_MAX_DEPTH) return false;
+            for (int s = 0; s < 8; ++s) {
+                if (!(bvh.nodes[i].valid_mask & (1u << s)) || (bvh.nodes[i].children[s] & LEAF_FLAG)) continue;
+                const uint32_t c = bvh.nodes[i].children[s];
+                if (seen[c]) return false;
+                seen[c] = 1;
+                stack.push_back({c, depth + 1u});
+            }
+        }
+    }
+    if (ray_width > 1u && !repack_wide(bvh, count, out, ray_width, root_ray)) return false;
+    if (packet_width > 1u) {
+        if (packet_width == ray_width) *root_packet = *root_ray;
+        else if (!repack_wide(bvh, count, out, packet_width, root_packet)) return false;
+    }
+    return true;
+}
+static bool repack_wide(const PtxBvh8& bvh, const std::vector<uint32_t>& count, std::vector<NodeRec>& out, uint32_t wide_width, uint32_t* root_wide) {
+    auto internal_word = [](uint32_t abs_unit, uint32_t cnt) { return abs_unit | ((cnt - 1u) << NODE_NCHILD_SHIFT); };
+    std::vector<RepackItem> list;
+    std::vector<uint32_t> words;
+    // ---- wide tree: replace an internal child by its own ordered list, largest surface area first, while the record
+    // stays within wide_width children; the depth-first order of the leaves is unchanged
+    const uint32_t width = std::min<uint32_t>(wide_width, 8u);
+    // iterative (explicit stack): build a record for `node`, then one for each of its remaining internal children
+    std::vector<std::pair<uint32_t, size_t>> todo;       // (reference node, position of the child word to patch: unit index * 64 + child k, or ~0 for the root)
+    todo.push_back({0u, ~(size_t)0});
+    std::vector<RepackItem> sub;
+    while (!todo.empty()) {
+        const auto [node, patch] = todo.back();
+        todo.pop_back();
+        ordered_children(bvh.nodes[node], list);
+        for (;;) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (size_t k = 0; k < list.size(); ++k) {
+                if (list[k].word & LEAF_FLAG) continue;
+                if (list.size() - 1 + count[list[k].word] > width) continue;
+                const float* b = list[k].box;
+                const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+                const float area = (dx * dy + dy * dz) + dz * dx;
+                if (!(area <= best_area)) { best_area = area; best = (int)k; }     // NaN areas are taken too: any choice is valid
+            }
+            if (best < 0) break;
+            ordered_children(bvh.nodes[list[best].word], sub);
+            list.erase(list.begin() + best);
+            list.insert(list.begin() + best, sub.begin(), sub.end());
+        }
+        const size_t rec = out.size();
+        if (rec + 2 > NODE_INDEX_MASK) return false;
+        out.resize(rec + (list.size() > 4 ? 2 : 1));
+        words.assign(list.size(), 0u);
+        for (size_t k = 0; k < list.size(); ++k) {
+            if (list[k].word & LEAF_FLAG) words[k] = list[k].word;
+            else todo.push_back({list[k].word, rec * 64 + k});      // patched when the child's record exists
+        }
+        fill_record(&out[rec], list, words, 0u);
+        const uint32_t my_word = internal_word((uint32_t)rec, (uint32_t)list.size());
+        if (patch == ~(size_t)0) *root_wide = my_word;
+        else {
+            const size_t prec = patch / 64, k = patch % 64;
+            float f; std::memcpy(&f, &my_word, 4);
+            out[prec + k / 4].c[2 * (k % 4) + 1].z = f;
+        }
+    }
     return true;
 }
 
@@ -1309,6 +1506,7 @@ static int32_t ensure_capacity(PtxContext* ctx, uint64_t n) {
     HIPCHK(dev_alloc(pool, &ctx->q[0], n)); HIPCHK(dev_alloc(pool, &ctx->q[1], n));
     HIPCHK(dev_alloc(pool, &ctx->q_shadow, 2 * n)); HIPCHK(dev_alloc(pool, &ctx->q_final, n));
     HIPCHK(dev_alloc(pool, &ctx->q_redo, n));
+    HIPCHK(dev_alloc(pool, &ctx->q_walk[0], n)); HIPCHK(dev_alloc(pool, &ctx->q_walk[1], n));
     ctx->capacity = n;
     return PTX_OK;
 }
@@ -1347,7 +1545,7 @@ static int32_t ensure_worklist(PtxContext* ctx, uint32_t w, uint32_t h) {
 }
 
 constexpr uint32_t SSS_POLL_EVERY = 8;
-enum { CLS_RAYGEN = 0, CLS_EXTEND, CLS_SHADE, CLS_SHADOW, CLS_ACCUM, CLS_OTHER, CLS_PACKET };
+enum { CLS_RAYGEN = 0, CLS_EXTEND, CLS_SHADE, CLS_SHADOW, CLS_ACCUM, CLS_OTHER, CLS_PACKET, CLS_WALK };
 struct ScopedEvent {
     PtxContext* ctx; int idx = -1;
     ScopedEvent(PtxContext* c, int cls) : ctx(c) {
@@ -1372,6 +1570,7 @@ static void drain_events(PtxContext* ctx) {
                 case CLS_SHADE: ctx->timings.shade_ms += ms; ctx->timings.shade_launches++; break;
                 case CLS_SHADOW: ctx->timings.shadow_ms += ms; ctx->timings.shadow_launches++; break;
                 case CLS_ACCUM: ctx->timings.accumulate_ms += ms; break;
+                case CLS_WALK: ctx->timings.walk_ms += ms; ctx->timings.walk_launches++; break;
                 default: ctx->timings.other_ms += ms; break;
             }
         }
@@ -1386,7 +1585,7 @@ static int32_t check_device_error(PtxContext* ctx) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->h_pinned[0] != 0) {
         HIPCHK(hipMemsetAsync(ctx->d_err, 0, 4, ctx->stream));
-        return fail(ctx, PTX_ERR_STACK_OVERFLOW, "traversal stack exceeded 64 entries on one BVH level (the reference would panic)");
+        return fail(ctx, PTX_ERR_STACK_OVERFLOW, "a traversal needed more than the 144 stack entries a ray has on the device (the reference panics beyond 64 per BVH level)");
     }
     return PTX_OK;
 }
@@ -1431,6 +1630,8 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
         return PTX_OK;
     }
     const bool sss = ctx->S.has_sss != 0;
+    // A subsurface walk takes one iteration per step (up to 64 per event) on top of the path's bounces: the iteration
+    // count is data dependent, the loop below polls the live counts.
     const uint32_t iter_cap = sss ? MAX_ITERS - 1 : std::min<uint32_t>(max_bounces, MAX_ITERS - 1);
     HIPCHK(hipMemsetAsync(ctx->ctrs, 0, sizeof(IterCtr) * (size_t)(sss ? MAX_ITERS : iter_cap + 1), ctx->stream));
     {
@@ -1449,6 +1650,8 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
     for (uint32_t it = 0; it < iter_cap; ++it) {
         uint32_t* qa = ctx->q[it & 1];
         uint32_t* qb = ctx->q[(it + 1) & 1];
+        uint32_t* qwa = ctx->q_walk[it & 1];          // subsurface walks in flight: their step rays are traced with qa
+        uint32_t* qwb = ctx->q_walk[(it + 1) & 1];
         IterCtr* c = ctx->ctrs + it;
         {
             // primary rays of neighbouring queue entries are coherent (a pixel's samples, or an 8x8 tile): packets
@@ -1458,14 +1661,22 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
                 if (st != PTX_OK) return st;
             } else {
                 ScopedEvent ev(ctx, CLS_EXTEND);
-                if (ctx->counting) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
-                else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                if (ctx->counting) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
             }
         }
         {
             ScopedEvent ev(ctx, CLS_SHADE);
-            if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, dim3(final_grid), dim3(SHADE_BLOCK)   /* counted: few blocks, each ends with 7 counter atomics per wave */, 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
-            else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(SHADE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
+            if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, dim3(final_grid), dim3(SHADE_BLOCK)   /* counted: few blocks, each ends with 7 counter atomics per wave */, 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, qwb, c, c + 1, max_bounces, ctx->d_counters);
+            else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(SHADE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, qwb, c, c + 1, max_bounces, ctx->d_counters);
+        }
+        if (sss && it > 0) {
+            // one state transition for every path in a subsurface event: continuing walks join qwb, finished events qb
+            // (and this iteration's shadow queue), dead paths q_final
+            ScopedEvent ev(ctx, CLS_WALK);
+            const int wg = (int)std::min<uint64_t>(256 * 64, (n + WALK_BLOCK - 1) / WALK_BLOCK);
+            if (ctx->counting) hipLaunchKernelGGL(k_sss_step<true>, dim3(std::min(wg, 256 * 8)), dim3(WALK_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qwa, qwb, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
+            else hipLaunchKernelGGL(k_sss_step<false>, dim3(wg), dim3(WALK_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qwa, qwb, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
         }
         {
             ScopedEvent ev(ctx, CLS_SHADOW);
@@ -1484,9 +1695,9 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
             // subsurface walks make the iteration count data dependent: poll the live count every few iterations (the
             // launches of an iteration whose queues are empty leave in microseconds; a host round trip per iteration
             // does not)
-            HIPCHK(hipMemcpyAsync(ctx->h_pinned + 1, &ctx->ctrs[it + 1].n_active, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(ctx->h_pinned + 16, &ctx->ctrs[it + 1], 16, hipMemcpyDeviceToHost, ctx->stream));     // n_active .. n_walk
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            if (ctx->h_pinned[1] == 0) { drained = true; break; }
+            if (ctx->h_pinned[16] == 0 && ctx->h_pinned[19] == 0) { drained = true; break; }
         }
     }
     HIPCHK(hipGetLastError());
@@ -1539,6 +1750,8 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
     if (const char* e = std::getenv("PTX_PACKET_SHADOW")) c->packet_shadow = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("PTX_PACKET_CAPACITY")) c->packet_capacity = std::max(8, std::min((int)std::strtol(e, nullptr, 10), PACKET_LDS + OVF_STACK));
     if (const char* e = std::getenv("PTX_PACKET_BATCH")) c->packet_batch = std::strtoul(e, nullptr, 10) != 0;
+    if (const char* e = std::getenv("PTX_WIDE_BVH")) c->packet_width = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), 8);
+    if (const char* e = std::getenv("PTX_WIDE_RAY_BVH")) c->ray_width = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), 8);
     if (const char* e = std::getenv("PTX_ADAPTIVE_BATCH")) {
         const unsigned long v = std::strtoul(e, nullptr, 10);
         if (v) c->adaptive_batch = (uint32_t)std::min<unsigned long>(v, 256);
@@ -1598,14 +1811,15 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
     std::vector<MeshRec> meshes(sc->n_meshes);
     std::vector<float> positions, normals, uvs;
     std::vector<uint32_t> indices;
-    uint32_t nrec = 0, tlas_root_word = 0;
-    std::vector<uint32_t> mesh_root_word(sc->n_meshes, 0u);
+    uint32_t tlas_root_word = 0, tlas_root_word_ray = 0, tlas_root_word_packet = 0;
+    std::vector<uint32_t> mesh_root_word(sc->n_meshes, 0u), mesh_root_word_ray(sc->n_meshes, 0u), mesh_root_word_packet(sc->n_meshes, 0u);
     if (sc->n_instances) {
-        if (!repack_bvh(sc->tlas, nodes, &nrec, &tlas_root_word)) return fail(ctx, PTX_ERR_INVALID, "TLAS is empty, too large or has a child word out of range");
+        if (!repack_bvh(sc->tlas, nodes, &tlas_root_word, ctx->ray_width, &tlas_root_word_ray, ctx->packet_width, &tlas_root_word_packet))
+            return fail(ctx, PTX_ERR_INVALID, "TLAS is empty, too large, not a tree or has a child word out of range");
         for (uint32_t i = 0; i < sc->tlas.n_primitive_indices; ++i)
             if (sc->tlas.primitive_indices[i] >= sc->n_instances) return fail(ctx, PTX_ERR_INVALID, "TLAS primitive index out of range");
     }
-    const uint32_t n_tlas_records = nrec;
+    const uint32_t n_tlas_records = (uint32_t)nodes.size();
     for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
         const PtxMesh& m = sc->meshes[mi];
         if (!m.positions || !m.indices || !m.n_triangles) return fail(ctx, PTX_ERR_INVALID, "mesh without geometry");
@@ -1626,7 +1840,8 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
         r.node_base = (uint32_t)nodes.size();
         r.tri_base = (uint32_t)tris.size();
         if (r.node_base > NODE_INDEX_MASK) return fail(ctx, PTX_ERR_UNSUPPORTED, "more than 2^29 node records");
-        if (!repack_bvh(m.bvh, nodes, &nrec, &mesh_root_word[mi])) return fail(ctx, PTX_ERR_INVALID, "mesh BVH is empty or has a child word out of range");
+        if (!repack_bvh(m.bvh, nodes, &mesh_root_word[mi], ctx->ray_width, &mesh_root_word_ray[mi], ctx->packet_width, &mesh_root_word_packet[mi]))
+            return fail(ctx, PTX_ERR_INVALID, "mesh BVH is empty, not a tree or has a child word out of range");
         for (uint32_t s = 0; s < m.bvh.n_primitive_indices; ++s) {
             const uint32_t t = m.bvh.primitive_indices[s];
             if (t >= m.n_triangles) return fail(ctx, PTX_ERR_INVALID, "mesh BVH primitive index out of range");
@@ -1654,7 +1869,7 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
         pack_cols(in.inverse_transform, &r.m[0]);
         r.m[3] = make_float4(m.bounds_min[0], m.bounds_min[1], m.bounds_min[2], m.bounds_max[0]);
         float nb, tb;
-        const uint32_t nb_word = mesh_root_word[in.blas_index];
+        const uint32_t nb_word = mesh_root_word_ray[in.blas_index];
         std::memcpy(&nb, &nb_word, 4);
         std::memcpy(&tb, &meshes[in.blas_index].tri_base, 4);
         r.m[4] = make_float4(m.bounds_max[1], m.bounds_max[2], nb, tb);
@@ -1699,8 +1914,15 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
     auto& pool = ctx->scene_allocs;
     HIPCHK(dev_upload(pool, &S.nodes, nodes)); HIPCHK(dev_upload(pool, &S.tlas_prims, tlas_prims)); HIPCHK(dev_upload(pool, &S.tris, tris));
     std::vector<InstRec> inst_tlas(tlas_prims.size());
-    for (size_t j = 0; j < tlas_prims.size(); ++j) inst_tlas[j] = inst[tlas_prims[j]];
+    std::vector<uint32_t> inst_root_faithful(tlas_prims.size()), inst_root_packet(tlas_prims.size());
+    for (size_t j = 0; j < tlas_prims.size(); ++j) {
+        inst_tlas[j] = inst[tlas_prims[j]];
+        inst_root_faithful[j] = mesh_root_word[sc->instances[tlas_prims[j]].blas_index];
+        inst_root_packet[j] = mesh_root_word_packet[sc->instances[tlas_prims[j]].blas_index];
+    }
     HIPCHK(dev_upload(pool, &S.inst_tlas, inst_tlas));
+    HIPCHK(dev_upload(pool, &S.inst_root_faithful, inst_root_faithful));
+    HIPCHK(dev_upload(pool, &S.inst_root_packet, inst_root_packet));
     HIPCHK(dev_upload(pool, &S.inst, inst)); HIPCHK(dev_upload(pool, &S.inst_shade, inst_shade)); HIPCHK(dev_upload(pool, &S.meshes, meshes));
     HIPCHK(dev_upload(pool, &S.positions, positions)); HIPCHK(dev_upload(pool, &S.normals, normals)); HIPCHK(dev_upload(pool, &S.uvs, uvs));
     HIPCHK(dev_upload(pool, &S.indices, indices)); HIPCHK(dev_upload(pool, &S.materials, materials)); HIPCHK(dev_upload(pool, &S.textures, textures));
@@ -1758,6 +1980,8 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
     S.sun_cos_angle = sc->sun.cos_angle; S.sun_pdf = sc->sun.pdf;
     S.n_tlas_nodes = sc->n_instances ? n_tlas_records : 0;
     S.tlas_root_word = tlas_root_word;
+    S.tlas_root_word_ray = tlas_root_word_ray;
+    S.tlas_root_word_packet = tlas_root_word_packet;
     S.has_sss = has_sss ? 1u : 0u;
     // shading triangles: built on the device from the pools just uploaded, one launch per mesh
     {
@@ -1822,7 +2046,7 @@ static int32_t render_to_images(PtxContext* ctx, uint32_t w, uint32_t h, uint32_
                 const int32_t ps = launch_primary_packets(ctx, ctx->q[0], ctx->ctrs, n);
                 if (ps != PTX_OK) return ps;
             } else
-                hipLaunchKernelGGL(k_extend<false>, dim3(tg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q[0], ctx->ctrs, ctx->ovf, ctx->d_counters, ctx->d_err);
+                hipLaunchKernelGGL(k_extend<false>, dim3(tg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q[0], (const uint32_t*)nullptr, ctx->ctrs, ctx->ovf, ctx->d_counters, ctx->d_err);
             hipLaunchKernelGGL(k_unshaded, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->P, n, d_rgb);
         }
     } else {
@@ -2244,7 +2468,7 @@ int32_t ptx_trace_batch_noalloc(PtxContext* ctx, const PtxRay* d_rays, uint64_t 
     HIPCHK(hipMemcpyAsync(ctx->h_pinned + 12, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->h_pinned[12] != 0)
-        return fail(ctx, PTX_ERR_STACK_OVERFLOW, "traversal stack exceeded 64 entries on one BVH level (the reference would panic)");
+        return fail(ctx, PTX_ERR_STACK_OVERFLOW, "a traversal needed more than the 144 stack entries a ray has on the device (the reference panics beyond 64 per BVH level)");
     return PTX_OK;
 }
 

@@ -27,11 +27,16 @@
 // carries no prefetch registers and the kernel fits more waves per SIMD.
 //
 // Order is preserved exactly through the unified stack:
-//   * a node visit pushes its hit INTERNAL children in ascending slot order,
-//     then its hit LEAF children in descending slot order on top, so the leaves
-//     pop first, in ascending slot order, before any deeper node — which is the
-//     reference's "test leaf slots immediately, push internal slots" order;
-//     internal entries pop in descending slot order, as in the reference;
+//   * a record lists its children in the order the reference's walk takes them
+//     (leaf slots ascending, then internal slots descending: pt_types.h); a node
+//     visit pushes the hit children in REVERSE list order, so they pop in list
+//     order: the leaves first, in ascending slot order, before any deeper node —
+//     the reference's "test leaf slots immediately, push internal slots" — then
+//     the internal children in descending slot order, as the reference's LIFO
+//     stack yields them.  Rays without NaN slabs walk the WIDE trees (up to 8
+//     children per record, same leaf order: pt_types.h says why that cannot
+//     change a hit); rays with NaN slabs and the counted kernels walk the
+//     faithful trees, one record per reference node;
 //   * the reference's per-slot cull `dist >= closest_t` (accel/bvh.rs:344-347)
 //     is applied when an entry is popped.  An internal child that an earlier
 //     leaf of the same node makes cullable is pushed anyway and dropped by the
@@ -75,6 +80,7 @@ constexpr int LDS_STACK = PT_LDS_STACK;
 constexpr int LEVEL_STACK_LIMIT = 64;                 // accel/bvh.rs:320,379
 // two levels of internal entries + per level: pending leaves (<= 4), TLAS remainder (1), marker (3)
 constexpr int OVF_STACK = 2 * LEVEL_STACK_LIMIT + 16 - LDS_STACK;
+constexpr int STACK_CAP = LDS_STACK + OVF_STACK;      // entries one lane's stack can hold (LDS part + HBM strip)
 constexpr int TRACE_BLOCK = 64;                       // one wave per block: traversal needs no barrier
 constexpr uint32_t REFILL_MIN_IDLE = PT_REFILL_MIN_IDLE, REFILL_MIN_IDLE_ANY = PT_REFILL_MIN_IDLE_ANY;   // refill a wave once this many lanes are idle
 #ifndef PT_RUN_THRESHOLD
@@ -195,7 +201,7 @@ template <bool ANY, bool CNT>
 struct Traverser {
     V3 o, d, inv;              // ray of the level being traversed
     float ct;                  // closest_t of that level (ANY: its ray.t_max)
-    int sp, lim;               // stack pointer; internal pushes fail at sp >= lim (level base + 64)
+    int sp;                    // stack pointer (one typed stack for the three levels)
     uint32_t tri_base;         // first TriRec of the mesh being traversed
     uint32_t m_tri;            // best hit inside the current instance (its t is `ct`)
     float m_u, m_v;
@@ -204,16 +210,18 @@ struct Traverser {
     uint32_t tri_cnt;          // TRI: triangles left in the leaf
     bool in_mesh, found, exact;
 
+    // which tree the current level is walked in: the faithful one for NaN-slab rays and for the counted kernels
+    PT_DEV bool faithful() const { return CNT || exact; }
     PT_DEV void begin(const SceneDev& S, V3 origin, V3 direction, float tmax) {
         o = origin; d = direction;
         inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);          // Ray::new (ray.rs:13-21)
         exact = ray_needs_exact(o, inv);
         ct = tmax;
-        sp = 0; lim = LEVEL_STACK_LIMIT; tri_base = 0;
+        sp = 0; tri_base = 0;
         m_tri = PTX_MISS; m_u = 0.0f; m_v = 0.0f;
         in_mesh = false; found = false;
         tri_cnt = 0;
-        pw = S.tlas_root_word;
+        pw = faithful() ? S.tlas_root_word : S.tlas_root_word_ray;
         // Bvh8::traverse_*: empty => None/false; the root is popped with dist 0.0: culled only if closest_t <= 0
         // (accel/bvh.rs:322-329)
         act = (S.n_tlas_nodes == 0 || (!ANY && 0.0f >= ct)) ? ACT_DONE : ACT_NODE;
@@ -240,45 +248,51 @@ struct Traverser {
     }
 
     // ---- ACT_NODE: node.intersect + the slot loop's pushes -----------------------------
-    // FOUR = false: no lane of this run has a 4-child record (the reference's builder never makes one; they only
-    // come from the chains built for wider nodes), so the fourth child's loads, test and push terms are compiled out.
-    template <bool EXACT, bool FOUR>
-    PT_DEV void do_node(const SceneDev& S, const StackRef& st, LaneCnt& lc, uint32_t& err, const float4 a0, const float4 a1,
-                        const float4 b0, const float4 b1, const float4 c0, const float4 c1) {
-        const float tmin = RAY_EPSILON;
-        const uint32_t nchild = ((pw >> NODE_NCHILD_SHIFT) & 3u) + 1u;
-        const float4* p = reinterpret_cast<const float4*>(&S.nodes[pw & NODE_INDEX_MASK]);
-        // children 0..2 were fetched by the caller (unused slots of a record are zero)
-        float4 d0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d1 = d0;
-        if (FOUR && nchild > 3u) { d0 = p[6]; d1 = p[7]; }
-        if (CNT) {
-            const uint32_t meta = __float_as_uint(a1.w);
-            lc.node_visits += (meta >> 4) & 1u;
-            lc.node_children += meta & 15u;
+    // One child: the box test (accel/bvh.rs:198-215 for that slot) and, on a hit, the push (do_node has made sure
+    // that the stack has room for all of the record's children).
+    template <bool EXACT>
+    PT_DEV void visit_child(const StackRef& st, const float4 lo, const float4 hi, bool valid) {
+        float te;
+        const bool h = box_test<EXACT>(lo, hi, o, inv, RAY_EPSILON, ct, &te) && valid;
+        if (h) {
+            const uint32_t w = __float_as_uint(hi.z);
+            st_write(st, sp, w, __float_as_uint(te));
+            ++sp;
         }
-        float te0, te1, te2, te3 = 0.0f;
-        const bool h0 = box_test<EXACT>(a0, a1, o, inv, tmin, ct, &te0);
-        const bool h1 = box_test<EXACT>(b0, b1, o, inv, tmin, ct, &te1) && nchild > 1u;
-        const bool h2 = box_test<EXACT>(c0, c1, o, inv, tmin, ct, &te2) && nchild > 2u;
-        bool h3 = false;
-        if (FOUR && nchild > 3u) h3 = box_test<EXACT>(d0, d1, o, inv, tmin, ct, &te3);
-        const uint32_t w0 = __float_as_uint(a1.z), w1 = __float_as_uint(b1.z), w2 = __float_as_uint(c1.z), w3 = __float_as_uint(d1.z);
+    }
+    // up to four children of one 128-B unit, last first; q0..q5 = children 0..2 of the unit, already in registers
+    template <bool EXACT, bool WIDE>
+    PT_DEV void visit_unit(const StackRef& st, const float4* q, uint32_t nb, const float4 q0, const float4 q1, const float4 q2,
+                           const float4 q3, const float4 q4, const float4 q5) {
+        if (WIDE && nb > 3u) { const float4 d0 = q[6], d1 = q[7]; visit_child<EXACT>(st, d0, d1, true); }
+        visit_child<EXACT>(st, q4, q5, nb > 2u);
+        visit_child<EXACT>(st, q2, q3, nb > 1u);
+        visit_child<EXACT>(st, q0, q1, true);
+    }
+    // WIDE = false: no lane of this run has a record with more than 3 children (the faithful tree of the reference's
+    // builder never has one), so the fourth child and the second unit are compiled out.
+    // r0..r5 = children 0..2 of the unit visited FIRST: the second unit when the record has one (children 4..6), else the first.
+    template <bool EXACT, bool WIDE>
+    PT_DEV void do_node(const SceneDev& S, const StackRef& st, LaneCnt& lc, uint32_t& err, const float4 r0, const float4 r1,
+                        const float4 r2, const float4 r3, const float4 r4, const float4 r5) {
+        const uint32_t nchild = ((pw >> NODE_NCHILD_SHIFT) & NODE_NCHILD_MASK) + 1u;
+        const float4* p = reinterpret_cast<const float4*>(&S.nodes[pw & NODE_INDEX_MASK]);
+        // the device stack (all levels of one ray share it) holds STACK_CAP entries; the reference's fixed arrays hold
+        // 64 per level and panic beyond (accel/bvh.rs:320,361,379,408)
+        if (sp + (int)nchild > STACK_CAP) { err = 1u; found = false; act = ACT_DONE; return; }
         act = ACT_POP;
-        // Internal children go on in ascending slot order (accel/bvh.rs:360-363), leaf children on top of them in
-        // descending order, so that the leaves pop first and in ascending slot order.  Every child's final
-        // position follows from the hit masks, so each child is written once.
-        const int i0 = (int)(h0 && !(w0 & LEAF_FLAG)), i1 = (int)(h1 && !(w1 & LEAF_FLAG)), i2 = (int)(h2 && !(w2 & LEAF_FLAG));
-        const int i3 = FOUR ? (int)(h3 && !(w3 & LEAF_FLAG)) : 0;
-        const int l0 = (int)(h0 && (w0 & LEAF_FLAG)), l1 = (int)(h1 && (w1 & LEAF_FLAG)), l2 = (int)(h2 && (w2 & LEAF_FLAG));
-        const int l3 = FOUR ? (int)(h3 && (w3 & LEAF_FLAG)) : 0;
-        const int n_int = i0 + i1 + i2 + i3;
-        if (sp + n_int > lim) { err = 1u; found = false; act = ACT_DONE; return; }
-        const int lb = sp + n_int;
-        if (h0) st_write(st, l0 ? lb + l3 + l2 + l1 : sp, w0, __float_as_uint(te0));
-        if (h1) st_write(st, l1 ? lb + l3 + l2 : sp + i0, w1, __float_as_uint(te1));
-        if (h2) st_write(st, l2 ? lb + l3 : sp + i0 + i1, w2, __float_as_uint(te2));
-        if (FOUR && h3) st_write(st, l3 ? lb : sp + i0 + i1 + i2, w3, __float_as_uint(te3));
-        sp = lb + l0 + l1 + l2 + l3;
+        if (WIDE && nchild > 4u) {
+            // a record of two units: its children 7..4 now (they are pushed first), its children 3..0 in the lane's next
+            // node action — the lane stays in ACT_NODE with the record's first unit as a 4-child record.  Two short
+            // visits instead of one long one keep the kernel at 80 VGPRs; only hosts with truly wide BVH8 nodes (the
+            // reference's builder stops at 3 children) and the PTX_WIDE_RAY_BVH experiment reach this.
+            visit_unit<EXACT, true>(st, p + 8, nchild - 4u, r0, r1, r2, r3, r4, r5);
+            pw = (pw & NODE_INDEX_MASK) | (3u << NODE_NCHILD_SHIFT);
+            act = ACT_NODE;
+        } else {
+            if (CNT) { const uint32_t meta = __float_as_uint(r1.w); lc.node_visits += (meta >> 4) & 1u; lc.node_children += meta & 15u; }
+            visit_unit<EXACT, WIDE>(st, p, nchild, r0, r1, r2, r3, r4, r5);
+        }
         if (CNT) lc.stack_hw = (uint32_t)sp > lc.stack_hw ? (uint32_t)sp : lc.stack_hw;
     }
 
@@ -309,7 +323,7 @@ struct Traverser {
     }
 
     // ---- ACT_ENTER: Instance::hit / hit_any head + the Blas-level box ---------------------
-    PT_DEV void do_enter(const SceneDev& S, const StackRef& st, LaneCnt& lc) {
+    PT_DEV void do_enter(const SceneDev& S, const StackRef& st, LaneCnt& lc, uint32_t& err) {
         const float tmin = RAY_EPSILON;
         const uint32_t start = pw & PRIM_START_MASK;
         const uint32_t count = ((pw >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
@@ -317,6 +331,7 @@ struct Traverser {
         const float4 ia = p[0], ib = p[1], ic = p[2], b0 = p[3], b1 = p[4];
         const uint32_t inst_idx = S.tlas_prims[start];
         // TLAS leaf: this primitive now, the rest after the instance has been left
+        if (sp + 4 > STACK_CAP) { err = 1u; found = false; act = ACT_DONE; return; }     // remainder + 3-entry marker
         if (count > 1u) st_write(st, sp++, LEAF_FLAG | ((count - 2u) << PRIM_COUNT_SHIFT) | (start + 1u), NEG_INF_BITS);
         if (CNT) { lc.prim_reads++; lc.inst_entries++; lc.node_visits++; lc.node_children++; }
         const V3 lo = xf_point(ia, ib, ic, o);
@@ -342,8 +357,8 @@ struct Traverser {
         exact = lexact;
         tri_base = __float_as_uint(b1.w);
         m_tri = PTX_MISS;
-        lim = sp + LEVEL_STACK_LIMIT;
-        pw = __float_as_uint(b1.z);      // record 0 of the mesh BVH (absolute), child count in the top bits
+        // root record of the mesh BVH (absolute), child count in the top bits: wide tree, or the faithful one
+        pw = faithful() ? S.inst_root_faithful[start] : __float_as_uint(b1.z);
         act = ACT_NODE;
     }
 
@@ -376,7 +391,6 @@ struct Traverser {
         inv = v3(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e1.x));
         exact = (pw & MARK_EXACT) != 0u;
         ct = ct_world;
-        lim = LEVEL_STACK_LIMIT;
         act = ACT_POP;
     }
 };
@@ -394,7 +408,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
     Traverser<ANY, CNT> tv;
     tv.act = ACT_IDLE;
     tv.exact = false; tv.in_mesh = false; tv.found = false;
-    tv.sp = 0; tv.lim = LEVEL_STACK_LIMIT; tv.pw = 0; tv.tri_cnt = 0; tv.tri_base = 0; tv.m_tri = PTX_MISS; tv.m_u = 0.0f; tv.m_v = 0.0f;
+    tv.sp = 0; tv.pw = 0; tv.tri_cnt = 0; tv.tri_base = 0; tv.m_tri = PTX_MISS; tv.m_u = 0.0f; tv.m_v = 0.0f;
     tv.ct = 0.0f; tv.o = v3(0.0f, 0.0f, 0.0f); tv.d = tv.o; tv.inv = tv.o;
     uint32_t my = 0;
     // Idle lanes claim queue entries with one wave-aggregated atomic as soon as REFILL_MIN_IDLE of them have
@@ -452,7 +466,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
             if (tv.act == ACT_EXIT) tv.do_exit(S, st, lc, src, sink, my);
         }
         if (ce == mx || ce >= (ANY ? TH_ANY : TH_ENTER)) {
-            if (tv.act == ACT_ENTER) tv.do_enter(S, st, lc);
+            if (tv.act == ACT_ENTER) tv.do_enter(S, st, lc, err);
         }
         // Triangle and node lanes fetch their records together and wait once: the two sections used to pay one
         // memory round trip each, and a wave spends more time waiting on these loads than issuing.
@@ -460,17 +474,22 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
         const bool f_node = (cn == mx || cn >= (ANY ? TH_ANY : TH_NODE)) && tv.act == ACT_NODE;
         // wave-uniform choice of the node-visit variant: x86 NaN rule only if some lane can produce NaNs,
         // fourth child only if some lane's record has one
-        const bool wave_special = __ballot(f_node && (tv.exact || (tv.pw >> NODE_NCHILD_SHIFT) == 3u)) != 0ull;
+        const uint32_t nch = (tv.pw >> NODE_NCHILD_SHIFT) & NODE_NCHILD_MASK;      // children - 1 (node lanes)
+        const bool wave_exact = __ballot(f_node && tv.exact) != 0ull;
+        const bool wave_wide = __ballot(f_node && nch >= 3u) != 0ull;
         float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
         if (f_tri || f_node) {
-            const float4* p = f_node ? reinterpret_cast<const float4*>(&S.nodes[tv.pw & NODE_INDEX_MASK])
+            // node lanes fetch the first three children of the unit they visit first (the second unit of a record that
+            // has one: its children are pushed first)
+            const float4* p = f_node ? reinterpret_cast<const float4*>(&S.nodes[(tv.pw & NODE_INDEX_MASK) + (nch >= 4u ? 1u : 0u)])
                                      : reinterpret_cast<const float4*>(&S.tris[tv.pw]);
             r0 = p[0]; r1 = p[1]; r2 = p[2];
             if (f_node) { r3 = p[3]; r4 = p[4]; r5 = p[5]; }
         }
         if (f_tri) tv.do_tri(lc, r0, r1, r2);
         if (f_node) {
-            if (wave_special) tv.template do_node<true, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
+            if (wave_exact) tv.template do_node<true, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
+            else if (wave_wide) tv.template do_node<false, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
             else tv.template do_node<false, false>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
         }
     }
@@ -513,6 +532,32 @@ PT_DEV uint2 pk_read(const StackRef& s, int i) {
     return v;
 }
 
+// one 128-B unit of a record for a packet: test its nb children for every ray that takes part, push the ones some ray
+// hit, last child first (every lane stores its own entry distance, +inf where its ray missed)
+PT_DEV void pk_unit(const StackRef& st, int& sp, bool act, bool ex, uint32_t nb, V3 o, V3 inv, float ct, const float4 a0, const float4 a1,
+                    const float4 b0, const float4 b1, const float4 c0, const float4 c1, const float4 d0, const float4 d1) {
+    constexpr uint32_t POS_INF_BITS = 0x7F800000u;
+    const float tmin = RAY_EPSILON;
+    float te0, te1, te2, te3 = 0.0f;
+    bool h0, h1, h2, h3 = false;
+    if (ex) {
+        h0 = box_test<true>(a0, a1, o, inv, tmin, ct, &te0);
+        h1 = box_test<true>(b0, b1, o, inv, tmin, ct, &te1);
+        h2 = box_test<true>(c0, c1, o, inv, tmin, ct, &te2);
+        if (nb > 3u) h3 = box_test<true>(d0, d1, o, inv, tmin, ct, &te3);
+    } else {
+        h0 = box_test<false>(a0, a1, o, inv, tmin, ct, &te0);
+        h1 = box_test<false>(b0, b1, o, inv, tmin, ct, &te1);
+        h2 = box_test<false>(c0, c1, o, inv, tmin, ct, &te2);
+        if (nb > 3u) h3 = box_test<false>(d0, d1, o, inv, tmin, ct, &te3);
+    }
+    h0 = h0 && act; h1 = h1 && act && nb > 1u; h2 = h2 && act && nb > 2u; h3 = h3 && act;
+    if (__ballot(h3) != 0ull) pk_write(st, sp++, __float_as_uint(d1.z), h3 ? __float_as_uint(te3) : POS_INF_BITS);
+    if (__ballot(h2) != 0ull) pk_write(st, sp++, __float_as_uint(c1.z), h2 ? __float_as_uint(te2) : POS_INF_BITS);
+    if (__ballot(h1) != 0ull) pk_write(st, sp++, __float_as_uint(b1.z), h1 ? __float_as_uint(te1) : POS_INF_BITS);
+    if (__ballot(h0) != 0ull) pk_write(st, sp++, __float_as_uint(a1.z), h0 ? __float_as_uint(te0) : POS_INF_BITS);
+}
+
 #ifndef PT_PACKET_CHUNK
 #define PT_PACKET_CHUNK 8
 #endif
@@ -520,7 +565,7 @@ constexpr uint32_t PACKET_CHUNK = PT_PACKET_CHUNK;
 template <bool ANY, class Src, class Sink>
 PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes, const TriRec* __restrict__ g_tris,
                           const InstRec* __restrict__ g_inst_tlas, const InstRec* __restrict__ g_inst, const uint32_t* __restrict__ g_tlas_prims,
-                          const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink, uint32_t& err,
+                          const uint32_t* __restrict__ g_root_faithful, const uint32_t* __restrict__ g_root_packet, const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink, uint32_t& err,
                           const int capacity = PACKET_LDS + OVF_STACK, uint32_t* redo_keys = nullptr, uint32_t* redo_count = nullptr,
                           uint32_t* stack_hw = nullptr) {
     constexpr uint32_t POS_INF_BITS = 0x7F800000u;
@@ -562,7 +607,8 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
         int sp = 0, marker_sp = -1;
         bool overflow = false;
         // Bvh8::traverse_closest: (root, 0.0) is popped first; a lane without a ray never takes part
-        if (S.n_tlas_nodes != 0u) pk_write(st, sp++, S.tlas_root_word, valid ? 0u : POS_INF_BITS);
+        // the packet walks ONE tree: the wide one unless one of its rays can produce NaN slabs (pt_types.h)
+        if (S.n_tlas_nodes != 0u) pk_write(st, sp++, __ballot(valid && exact) != 0ull ? S.tlas_root_word : S.tlas_root_word_packet, valid ? 0u : POS_INF_BITS);
         while (sp > 0) {
             hw = sp > hw ? sp : hw;
             --sp;
@@ -598,7 +644,7 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
             // part in the entries it pushed (distance below +inf) until it has found its hit
             const bool act = ANY ? (!found && e.y != POS_INF_BITS) : !(__uint_as_float(e.y) >= ct);
             if (__ballot(act) == 0ull) continue;
-            if (sp + 6 > capacity) {
+            if (sp + 10 > capacity) {
                 // The packet's stack is the union of 64 rays' stacks and can outgrow what any one of them needs.  With a
                 // redo queue the packet's rays are handed to the per-ray kernel (which starts them from scratch and
                 // overwrites whatever this packet wrote); without one it is an error.
@@ -653,43 +699,27 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                     tri_base = __float_as_uint(b1.w);
                     marker_sp = sp;
                     pk_write(st, sp++, 0u, 0u);
-                    pk_write(st, sp++, __float_as_uint(b1.z), enter ? 0u : POS_INF_BITS);
+                    pk_write(st, sp++, (__ballot(enter && lexact) != 0ull ? g_root_faithful : g_root_packet)[start], enter ? 0u : POS_INF_BITS);
                     if (enter) { o = lo; d = ld; inv = linv; exact = lexact; ct = PT_INF; m_tri = PTX_MISS; }
                     in_mesh = true;
                 }
             } else {
-                // ---- node.intersect for every ray that takes part + the slot loop's pushes
-                const uint32_t nchild = ((word >> NODE_NCHILD_SHIFT) & 3u) + 1u;
+                // ---- node.intersect for every ray that takes part + the slot loop's pushes: the hit children in
+                // reverse list order, so that they pop in list order (leaf slots ascending, internal slots descending)
+                const uint32_t nchild = ((word >> NODE_NCHILD_SHIFT) & NODE_NCHILD_MASK) + 1u;      // wave-uniform
                 const float4* p = reinterpret_cast<const float4*>(&g_nodes[word & NODE_INDEX_MASK]);
-                const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3], c0 = p[4], c1 = p[5];
-                float4 d0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d1 = d0;
-                if (nchild > 3u) { d0 = p[6]; d1 = p[7]; }
-                float te0, te1, te2, te3 = 0.0f;
-                bool h0, h1, h2, h3 = false;
-                if (__ballot(act && exact) != 0ull) {
-                    h0 = box_test<true>(a0, a1, o, inv, tmin, ct, &te0);
-                    h1 = box_test<true>(b0, b1, o, inv, tmin, ct, &te1);
-                    h2 = box_test<true>(c0, c1, o, inv, tmin, ct, &te2);
-                    if (nchild > 3u) h3 = box_test<true>(d0, d1, o, inv, tmin, ct, &te3);
-                } else {
-                    h0 = box_test<false>(a0, a1, o, inv, tmin, ct, &te0);
-                    h1 = box_test<false>(b0, b1, o, inv, tmin, ct, &te1);
-                    h2 = box_test<false>(c0, c1, o, inv, tmin, ct, &te2);
-                    if (nchild > 3u) h3 = box_test<false>(d0, d1, o, inv, tmin, ct, &te3);
+                const bool ex = __ballot(act && exact) != 0ull;
+                if (nchild > 4u) {
+                    const float4* q = p + 8;
+                    const float4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3], c0 = q[4], c1 = q[5], d0 = q[6], d1 = q[7];
+                    pk_unit(st, sp, act, ex, nchild - 4u, o, inv, ct, a0, a1, b0, b1, c0, c1, d0, d1);
                 }
-                h0 = h0 && act; h1 = h1 && act && nchild > 1u; h2 = h2 && act && nchild > 2u; h3 = h3 && act;
-                const uint32_t w0 = __float_as_uint(a1.z), w1 = __float_as_uint(b1.z), w2 = __float_as_uint(c1.z), w3 = __float_as_uint(d1.z);
-                const bool any0 = __ballot(h0) != 0ull, any1 = __ballot(h1) != 0ull, any2 = __ballot(h2) != 0ull, any3 = __ballot(h3) != 0ull;
-                // internal children in ascending slot order (accel/bvh.rs:360-363), leaf children on top in descending
-                // order so that they pop first and in slot order
-                if (any0 && !(w0 & LEAF_FLAG)) pk_write(st, sp++, w0, h0 ? __float_as_uint(te0) : POS_INF_BITS);
-                if (any1 && !(w1 & LEAF_FLAG)) pk_write(st, sp++, w1, h1 ? __float_as_uint(te1) : POS_INF_BITS);
-                if (any2 && !(w2 & LEAF_FLAG)) pk_write(st, sp++, w2, h2 ? __float_as_uint(te2) : POS_INF_BITS);
-                if (any3 && !(w3 & LEAF_FLAG)) pk_write(st, sp++, w3, h3 ? __float_as_uint(te3) : POS_INF_BITS);
-                if (any3 && (w3 & LEAF_FLAG)) pk_write(st, sp++, w3, h3 ? __float_as_uint(te3) : POS_INF_BITS);
-                if (any2 && (w2 & LEAF_FLAG)) pk_write(st, sp++, w2, h2 ? __float_as_uint(te2) : POS_INF_BITS);
-                if (any1 && (w1 & LEAF_FLAG)) pk_write(st, sp++, w1, h1 ? __float_as_uint(te1) : POS_INF_BITS);
-                if (any0 && (w0 & LEAF_FLAG)) pk_write(st, sp++, w0, h0 ? __float_as_uint(te0) : POS_INF_BITS);
+                {
+                    const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3], c0 = p[4], c1 = p[5];
+                    float4 d0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d1 = d0;
+                    if (nchild > 3u) { d0 = p[6]; d1 = p[7]; }
+                    pk_unit(st, sp, act, ex, nchild > 4u ? 4u : nchild, o, inv, ct, a0, a1, b0, b1, c0, c1, d0, d1);
+                }
             }
         }
         if (overflow) {

@@ -5,31 +5,41 @@
 
 namespace ptd {
 
-// ---- BVH node record: 128 B = one L2 line, up to 4 children ------------------
+// ---- BVH node record: one or two 128-B units (one L2 line each), up to 8 children ------------
 // The reference's Bvh8Node stores 8 full-precision child boxes SoA in 256 B
 // (accel/bvh.rs:86-98), of which its own builder only ever fills 1-3
-// (SURVEY.md F8b).  The device record keeps the surviving slots, in slot
-// order, with the same f32 values: child k is two float4
+// (SURVEY.md F8b).  A device record keeps the valid slots with the same f32
+// values, child k as two float4
 //   c[2k]   = (min.x, min.y, min.z, max.x)
 //   c[2k+1] = (max.y, max.z, child_word, meta)
-// child_word: bit31 = leaf; leaf = 1<<31 | (count-1)<<24 | prim_start (start
-// relative to the owning BVH's leaf array, as in the reference); internal =
-// (children_in_target_record - 1) << 29 | ABSOLUTE record index in
-// SceneDev::nodes (mesh BVHs are stored once, so the index can be baked at
-// upload) — the parent says how many children the child record holds.
-// meta (child 0 only, counters): bits 0-3 = popcount(valid_mask) of the
-// reference node, bit 4 = this record starts a reference node.
-// A reference node with 5-8 valid slots (a host with a true 8-wide collapse;
-// the reference's own builder never fills more than 3) becomes a chain
-// [c0 c1 c2 P] -> P = [c3 c4 c5 P'] -> ...: P is a pseudo child with an
-// unbounded box placed LAST, so it pops first, its leaves are tested right
-// after c0..c2's and its internal children end up above theirs — the slot
-// order of the original node.
+// in VISIT ORDER: the reference tests the leaf slots of a node at once, in ascending slot order, and pushes the
+// internal slots, which its LIFO stack then pops in descending slot order (accel/bvh.rs:339-363) — a depth-first walk
+// that takes a node's children in the order [leaf slots ascending, internal slots descending].  Records list their
+// children in exactly that order, so the traversal is one rule: push the hit children in reverse list order, pop.
+// A node with <= 4 children is one unit, with 5-8 two consecutive units (children 4-7 in the second).
+// child_word: bit31 = leaf; leaf = 1<<31 | (count-1)<<24 | prim_start (start relative to the owning BVH's leaf array,
+// as in the reference); internal = (children_of_target_record - 1) << 28 | ABSOLUTE unit index in SceneDev::nodes —
+// the parent says how many children the child record holds.
+// meta (child 0 only, counters): bits 0-3 = popcount(valid_mask) of the reference node, bit 4 = this record is a
+// reference node (set in the faithful tree, clear in the wide tree).
+//
+// Every BVH is stored in two forms.  The FAITHFUL tree has one record per reference node.  A WIDE tree is an
+// order-preserving collapse of it: an internal child is replaced, in place, by that child's own list, largest
+// surface area first, until a record holds 8 children.  Substituting a list for its parent keeps the depth-first
+// order of the LEAVES unchanged, and that order is all the result depends on: in the reference a leaf's primitives
+// are tested iff the ray hits the leaf's box and `t_enter < closest_t` at the moment the walk reaches it — the tests
+// of its ancestors are implied, because child boxes are exact min/max unions (an ancestor's slab interval contains
+// the leaf's, also after f32 rounding, which is monotone) and closest_t only shrinks.  That argument needs ordered
+// comparisons, so rays that can produce NaN slabs (a zero direction component or a non-finite origin: 0 * inf) walk
+// the faithful tree, as do the counted kernels, whose event counts must be the reference's.  The packet kernels walk
+// an 8-wide tree (one record fetch serves the wave's 64 rays); the per-ray kernels walk the faithful tree, because they
+// are VALU-issue bound and wider records mean more box tests per ray (measured: DESIGN.md).
 struct NodeRec { float4 c[8]; };
-static_assert(sizeof(NodeRec) == 128, "node record must be one 128-byte line");
+static_assert(sizeof(NodeRec) == 128, "node record unit must be one 128-byte line");
 
 constexpr uint32_t LEAF_FLAG = 0x80000000u;
-constexpr uint32_t NODE_NCHILD_SHIFT = 29;
+constexpr uint32_t NODE_NCHILD_SHIFT = 28;
+constexpr uint32_t NODE_NCHILD_MASK = 7u;
 constexpr uint32_t NODE_INDEX_MASK = (1u << NODE_NCHILD_SHIFT) - 1u;
 constexpr uint32_t PRIM_START_MASK = 0x00FFFFFFu;
 constexpr uint32_t PRIM_COUNT_SHIFT = 24;
@@ -46,7 +56,7 @@ static_assert(sizeof(TriRec) == 48, "triangle record");
 // ---- instance record: 128 B ---------------------------------------------------
 //   m[0..2] inverse_transform columns packed (x.xyz,y.x | y.yz,z.xy | z.z,w.xyz)
 //   m[3]    (bounds_min.xyz, bounds_max.x)      -- the Blas-level item box
-//   m[4]    (bounds_max.y, bounds_max.z, mesh root record | (root children - 1) << 29, tri_base)
+//   m[4]    (bounds_max.y, bounds_max.z, root word of the mesh BVH in the per-ray kernels' tree, tri_base)   (other trees: SceneDev::inst_root_*)
 //   m[5..7] transform columns packed like m[0..2] (read only on an accepted hit)
 struct InstRec { float4 m[8]; };
 static_assert(sizeof(InstRec) == 128, "instance record");
@@ -88,6 +98,8 @@ struct SceneDev {
     const TriRec* tris;
     const InstRec* inst;           // by instance id
     const InstRec* inst_tlas;      // the same records in TLAS primitive_indices order (one load fewer per entry)
+    const uint32_t* inst_root_faithful;   // faithful-tree root word of each entry of inst_tlas (NaN-slab rays, counted kernels)
+    const uint32_t* inst_root_packet;     // wide-tree root word the packet kernels enter the instance's mesh BVH through
     const InstShade* inst_shade;
     const MeshRec* meshes;
     const ShadeTri* shade_tris;
@@ -119,7 +131,9 @@ struct SceneDev {
     const float* bn_lens;
     uint32_t bn_size;
     uint32_t n_tlas_nodes;         // 0 = empty TLAS (Tlas::build with no instances)
-    uint32_t tlas_root_word;       // record 0 | (children - 1) << 29
+    uint32_t tlas_root_word;       // faithful TLAS: record 0 | (children - 1) << 28
+    uint32_t tlas_root_word_ray;   // TLAS the per-ray kernels walk (== tlas_root_word unless PTX_WIDE_RAY_BVH asks for a collapse)
+    uint32_t tlas_root_word_packet;   // wide TLAS of the packet kernels (== tlas_root_word when the collapse is off)
     uint32_t has_sss;
 };
 

@@ -146,6 +146,45 @@ def test_full_detail_packet_overflow_takes_the_redo_road(pkg, oracle_det, full_s
     assert np.array_equal(bits(c), bits(g))
 
 
+@pytest.mark.parametrize("ray_width,packet_width", [(8, 8), (4, 0), (5, 3)])
+def test_collapsed_trees_do_not_change_a_hit(pkg, oracle_det, full_scenes, monkeypatch, ray_width, packet_width):
+    """The kernels may walk an order-preserving collapse of the reference's tree (csrc/device/pt_types.h: an internal
+    child replaced in place by its own child list keeps the depth-first order of the leaves, which is all a result
+    depends on).  By default only the packet kernels do (8 children per record); here the per-ray kernels walk
+    collapsed trees too, at several widths, on the deep scenes — per-ray, as packets, and through a frame."""
+    abi = pkg._abi
+    monkeypatch.setenv("PTX_WIDE_RAY_BVH", str(ray_width))
+    monkeypatch.setenv("PTX_WIDE_BVH", str(packet_width))
+    lp = pkg.HipRenderLoop(0)
+    monkeypatch.setenv("PTX_PACKET_BATCH", "1")
+    lpk = pkg.HipRenderLoop(0)
+    for name in ("bistro_like", "instanced_stress"):
+        sc = full_scenes(name)
+        w, h = 320, 180
+        cam = sc.default_camera(w / h)
+        osc = oracle_det.scene(sc)
+        prim = osc.primary_rays(cam, w, h, 5)
+        hc = osc.trace_closest(prim)
+        for rays in (prim, secondary_rays(abi, osc, prim, hc, 3)):
+            c, ca = osc.trace_closest(rays), osc.trace_any(rays)
+            for loop_ in (lp, lpk):
+                assert np.array_equal(loop_.trace_closest(sc, rays).view(np.uint8), c.view(np.uint8)), (name, ray_width, packet_width)
+                assert np.array_equal(loop_.trace_any(sc, rays), ca), (name, ray_width, packet_width)
+        img = osc.render_pass(cam, 128, 72, 2, FULL[name][1])
+        assert np.array_equal(bits(lp.render_pass(sc, cam, pkg.PathTracer(FULL[name][1]), 128, 72, 2)), bits(img))
+    # rays that can produce NaN slabs (zero direction components, origins on slab planes) take the faithful tree
+    sc = pkg.Scene.procedural("cornell", 1, 1.0, 0)
+    osc = oracle_det.scene(sc)
+    grid = [(ox, oy, oz, *d) for ox in (-1.0, 0.0, 0.3, 1.0) for oy in (0.0, 0.6, 2.0) for oz in (-1.0, 0.0, 0.35, 2.5)
+            for d in ((1, 0, 0), (0, -1, 0), (0, 0, 1), (1, 1, 0), (0, -1, 1), (-0.0, 0.0, -1.0), (0.3, -0.2, -1.0))]
+    r = np.array(grid, dtype=np.float32)
+    a = np.zeros(len(r), dtype=abi.ray_dtype())
+    a["origin"], a["direction"], a["t_max"] = r[:, :3], r[:, 3:], np.inf
+    for loop_ in (lp, lpk):
+        assert np.array_equal(loop_.trace_closest(sc, a).view(np.uint8), osc.trace_closest(a).view(np.uint8))
+        assert np.array_equal(loop_.trace_any(sc, a), osc.trace_any(a))
+
+
 def test_c5_uniform_plus_adaptive_frame_bit_exact(pkg, loop, oracle_det, full_scenes):
     """BASELINE config 5 on its real scene: uniform passes (a pixel-major batch), then adaptive passes in flight,
     against the oracle's pass-at-a-time AdaptiveFramebuffer."""
