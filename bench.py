@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    # one-GPU prediction of an N-GPU frame: render every rank's tile partition in turn on this card (no collective)
+    ap.add_argument("--emulate-world", type=int, default=0)
+    ap.add_argument("--adaptive-cap", type=int, default=0)  # with --emulate-world: adaptive phase up to this many spp (BASELINE config 5: 256)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -258,12 +261,59 @@ def main():
         "roofline": roofline,
     }
 
+    if world == 1 and args.emulate_world > 1:
+        out["emulated_world"] = emulate_world(pkg, loop, fb, scene, cam, renderer, spp, args, sec_per_frame)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, scene, cam, w, h, args.bounces, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def emulate_world(pkg, loop, fb, scene, cam, renderer, spp, args, sec_one_gpu):
+    """What an N-GPU frame would cost, measured on ONE card: each rank's partition (8x8 tiles, tile % N == rank) is
+    rendered in turn with everything else as in the real run.  Ranks do not talk during a frame (the exchange is one
+    all-gather at the end), so the N-GPU frame time is the slowest rank's time plus the exchange.
+      load balance          max / mean of the rank times
+      short-queue overhead  sum of the rank times / the 1-GPU frame time (a rank's queues are N times shorter)
+      adaptive frames       per-rank adaptive sample counts: how evenly the interleave spreads the noisy pixels"""
+    n = args.emulate_world
+    w, h = args.width, args.height
+    cfg = pkg.AdaptiveSamplingConfig(64, 0.001) if args.adaptive_cap > spp else None      # app.rs:139-143
+    times, adaptive_samples, passes = [], [], []
+
+    def one(rank_):
+        loop.set_partition(rank_, n)
+        t0 = time.perf_counter()
+        r, p = pkg.render.render_frame_distributed(lambda v: int(v), loop, fb, scene, cam, renderer, spp, adaptive=cfg, max_spp=args.adaptive_cap)
+        loop.sync()
+        return time.perf_counter() - t0, r, p
+
+    try:
+        full_t = None
+        if cfg is not None:           # the 1-GPU reference for an adaptive frame is measured here (the bench's own frames are uniform)
+            loop.set_partition(0, 1)
+            one_ = lambda: (pkg.render.render_frame_distributed(lambda v: int(v), loop, fb, scene, cam, renderer, spp, adaptive=cfg, max_spp=args.adaptive_cap), loop.sync())
+            one_()
+            t0 = time.perf_counter(); one_(); full_t = time.perf_counter() - t0
+        for r_ in range(n):
+            one(r_)                   # warm-up: work list and path state for this partition
+            dt, rendered, p = one(r_)
+            times.append(dt); adaptive_samples.append(rendered); passes.append(p)
+    finally:
+        loop.set_partition(0, 1)
+    ref = full_t if full_t is not None else sec_one_gpu
+    exch_bytes = pkg.render.tiles_bytes(w, h, n) * (n - 1)            # what one rank receives in the all-gather
+    exch_s = exch_bytes / 153e9                                       # one xGMI link (point-to-point, ~153 GB/s): pessimistic, 7 links can run in parallel
+    mx, mean = max(times), sum(times) / n
+    return {"world": n, "rank_s": [round(t, 4) for t in times], "max_over_mean": round(mx / mean, 4),
+            "sum_over_one_gpu_frame": round(sum(times) / ref, 4), "one_gpu_frame_s": round(ref, 4),
+            "exchange_bytes_received_per_rank": exch_bytes, "exchange_s_one_link": round(exch_s, 6),
+            "predicted_frame_s": round(mx + exch_s, 4), "predicted_speedup": round(ref / (mx + exch_s), 3),
+            "predicted_efficiency": round(ref / (mx + exch_s) / n, 4),
+            "adaptive": None if cfg is None else {"cap_spp": args.adaptive_cap, "samples_per_rank": adaptive_samples, "passes_per_rank": passes,
+                                                  "max_over_mean_samples": round(max(adaptive_samples) / max(1.0, sum(adaptive_samples) / n), 4)}}
 
 
 def cpu_baseline(pkg, scene, cam, w, h, bounces, budget_s):

@@ -186,4 +186,11 @@ extern "C" {
                             max_spp: u32, out_mean: *mut f32, out_counts: *mut u32, out_stats: *mut PtxFrameStats) -> i32;
     pub fn ptx_sync(ctx: *mut PtxContext) -> i32;
     pub fn ptx_trace_batch(ctx: *mut PtxContext, rays: *const PtxRay, n: u64, mode: i32, out_hits: *mut PtxHitRecord, out_any: *mut u8) -> i32;
+    /// `ptx_trace_batch` on caller-owned DEVICE buffers, no allocation inside the call (at most 2^24 rays).
+    pub fn ptx_trace_batch_noalloc(ctx: *mut PtxContext, d_rays: *const PtxRay, n: u64, mode: i32, d_out_hits: *mut PtxHitRecord, d_out_any: *mut u8) -> i32;
+    /// Multi-GPU exchange: this rank's own tiles as packed records into device memory of `ptx_fb_tiles_bytes` bytes
+    /// (one all-gather moves them), and the scatter of another rank's block into this context's framebuffer.
+    pub fn ptx_fb_tiles_bytes(width: u32, height: u32, world: u32) -> u64;
+    pub fn ptx_fb_export_tiles_dev(ctx: *mut PtxContext, d_out: *mut core::ffi::c_void, capacity_bytes: u64) -> i32;
+    pub fn ptx_fb_import_tiles_dev(ctx: *mut PtxContext, d_in: *const core::ffi::c_void, src_rank: u32, world: u32) -> i32;
 }

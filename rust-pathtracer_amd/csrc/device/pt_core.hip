@@ -1266,6 +1266,7 @@ struct PtxContext {
     // bound and a wider record means more box tests per ray: extend 368 -> 402 ms at 4, 550 ms at 8 with 5 waves/SIMD)
     uint32_t packet_width = 8, ray_width = 0;     // PTX_WIDE_BVH, PTX_WIDE_RAY_BVH
     uint32_t adaptive_batch = 32;   // adaptive passes traced together by ptx_fb_adaptive_passes (PTX_ADAPTIVE_BATCH)
+    bool adaptive_batch_auto = true;   // no PTX_ADAPTIVE_BATCH: start at 32 and double (up to 256) while >= 90 % of a batch's speculative samples were kept
     bool counting = false, profiling = false;
     struct Ev { hipEvent_t a, b; int cls; };
     std::vector<Ev> events;
@@ -1754,7 +1755,7 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
     if (const char* e = std::getenv("PTX_WIDE_RAY_BVH")) c->ray_width = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), 8);
     if (const char* e = std::getenv("PTX_ADAPTIVE_BATCH")) {
         const unsigned long v = std::strtoul(e, nullptr, 10);
-        if (v) c->adaptive_batch = (uint32_t)std::min<unsigned long>(v, 256);
+        if (v) { c->adaptive_batch = (uint32_t)std::min<unsigned long>(v, 256); c->adaptive_batch_auto = false; }
     }
     if (device_index < NOALLOC_MAX_DEVICES) {
         // once per device, with that device current (set above)
@@ -2234,6 +2235,7 @@ int32_t ptx_fb_adaptive_passes(PtxContext* ctx, const PtxAdaptiveConfig* cfg, ui
     uint32_t* d_count = reinterpret_cast<uint32_t*>(&ctx->ctrs[CTR_ADAPTIVE]);
     const int grid = (int)std::min<uint32_t>(2048, (n + 255) / 256);
     uint32_t passes = 0; uint64_t rendered = 0;
+    uint32_t batch = ctx->adaptive_batch;
     while (passes < max_passes) {
         HIPCHK(hipMemsetAsync(d_count, 0, sizeof(IterCtr), ctx->stream));
         hipLaunchKernelGGL(k_noise_keys, dim3(grid), dim3(256), 0, ctx->stream, ctx->wl_pixel, n, ctx->fb_sum, ctx->fb_sum_sq, ctx->fb_counts,
@@ -2245,7 +2247,7 @@ int32_t ptx_fb_adaptive_passes(PtxContext* ctx, const PtxAdaptiveConfig* cfg, ui
         // passes in flight: every noisy pixel gets `b` speculative samples; k_accumulate_adaptive keeps the ones the
         // pass-at-a-time loop would have taken.  Device counters would include the dropped samples, and a truncated
         // work list couples the pixels, so both cases go one pass at a time.
-        const uint32_t b = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(ctx->adaptive_batch, max_passes - passes),
+        const uint32_t b = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(batch, max_passes - passes),
                                                         std::max<uint64_t>(1, ctx->max_paths_in_flight / n_noisy));
         if (ctx->counting || b <= 1 || (uint64_t)n_noisy > cfg->max_samples_per_pass) {
             uint64_t r = 0;
@@ -2274,6 +2276,12 @@ int32_t ptx_fb_adaptive_passes(PtxContext* ctx, const PtxAdaptiveConfig* cfg, ui
         const uint64_t applied = (uint64_t)ctx->h_pinned[10] | ((uint64_t)ctx->h_pinned[11] << 32);
         passes += applied_max; rendered += applied;
         if (applied_max < b) break;    // the next pass would find no noisy pixel
+        // longer batches keep the queues long when few pixels are left (or a rank owns an eighth of them); they only
+        // pay while pixels rarely converge inside a batch, i.e. while nearly every speculative sample is kept
+        if (ctx->adaptive_batch_auto) {
+            if (applied * 10 >= (uint64_t)n_noisy * b * 9) batch = std::min<uint32_t>(batch * 2u, 256u);
+            else if (applied * 2 < (uint64_t)n_noisy * b) batch = std::max<uint32_t>(batch / 2u, 8u);
+        }
     }
     *out_passes = passes; *out_rendered = rendered;
     return check_device_error(ctx);
