@@ -72,7 +72,12 @@ typedef struct PtxBvh8 {
  * (shape/triangle_mesh.rs:6-14; the loader never builds anything else:
  * loader/gltf.rs:300-302).  `bounds_*` is the mesh's unpadded position bounds
  * (triangle_mesh.rs:56-61) == slot 0 of the one-node item BVH of the Blas
- * (accel/mod.rs:27-52). */
+ * (accel/mod.rs:27-52).
+ * NOT SUPPORTED: a `Blas` built over several items (`Blas::build(vec![a, b, ..])`,
+ * accel/mod.rs:27-52, which the type allows and nothing in the reference does).
+ * Its item-level BVH8 would be a third tree between instance and mesh; this
+ * descriptor has no place for it, so such a host must give every item its own
+ * PtxMesh + PtxInstance (same image, different instance ids) or stay on the CPU. */
 typedef struct PtxMesh {
     const float* positions;  uint32_t n_positions;   /* xyz triples            */
     const float* normals;    uint32_t n_normals;     /* xyz triples, 0 = none  */

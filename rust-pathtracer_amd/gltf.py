@@ -13,8 +13,10 @@ Mirrors `src/raytracer/loader/gltf.rs`:
   * the first perspective camera in node order: position = column 3, forward = -normalize(column 2),
     fov = yfov in degrees (:311-338).
 
-Image files are decoded with PIL (the reference uses the `image` crate: same pixels for 8-bit PNG/JPEG; PIL hands 16-bit
-RGB PNGs over as 8-bit, which the loader reports in `GltfScene.notes`).  Node TRS -> matrix uses the usual
+Image files are decoded with PIL, the reference with the `image` crate: PARITY UNPINNED for the texel values.  PNG
+decoding is lossless, so 8-bit RGB(A) PNGs give the same pixels; JPEG does not define its IDCT bit for bit, so PIL's
+(libjpeg) texels can differ from the `image` crate's by a few levels; PIL hands 16-bit RGB PNGs over as 8-bit.  The
+loader says so per image in `GltfScene.notes` (JPEG and 16-bit cases, like the grey formats).  Node TRS -> matrix uses the usual
 T * R(q) * S in float32; the `gltf` crate's exact operation order is not available here, so transforms of TRS nodes are
 "parity unpinned" to the last ulp — nodes that carry a `matrix` pass through bit for bit.
 """
@@ -201,7 +203,13 @@ def _decode_image(doc, img, convert_srgb, lut, notes, index):
     else:
         raise GltfError(f"image {index} has neither uri nor bufferView")
     im = Image.open(io.BytesIO(data))
+    fmt = (im.format or "").upper()
+    bits16 = im.mode.startswith("I;16") or getattr(im, "png", None) is not None and im.info.get("bits", 8) == 16
     im.load()
+    if fmt in ("JPEG", "MPO"):
+        notes.append(f"image {index}: JPEG decoded by PIL/libjpeg; texels may differ from the `image` crate's decoder by a few levels (parity unpinned)")
+    if bits16:
+        notes.append(f"image {index}: 16-bit PNG reduced to 8 bits by PIL (the reference keeps 16-bit RGB as value / 65535)")
     if im.mode == "P":                                  # the `image` crate expands palettes to RGB(A)8
         im = im.convert("RGBA" if "transparency" in im.info else "RGB")
     w, h = im.size

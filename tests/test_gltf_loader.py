@@ -72,3 +72,38 @@ def test_gltf_errors(pkg, tmp_path):
     p.write_bytes(b"glTF" + (1).to_bytes(4, "little") + (12).to_bytes(4, "little"))
     with pytest.raises(pkg.gltf.GltfError):
         pkg.gltf.load_gltf(str(p))
+
+
+def test_matrix_only_nodes_pass_through_bit_for_bit(pkg, tmp_path):
+    """Nodes that carry a `matrix` (no TRS decomposition involved): the global transform is `parent * local`
+    (loader/gltf.rs:210-235) in glam's f32 operation order — ((a.x_axis*b.x + a.y_axis*b.y) + a.z_axis*b.z) + a.w_axis*b.w
+    per column — and must come out bit for bit."""
+    import base64
+    import json
+    rng = np.random.default_rng(4)
+    a = np.eye(4, dtype=np.float32); a[:3, :] = rng.normal(size=(3, 4)).astype(np.float32)      # row-major, affine
+    b = np.eye(4, dtype=np.float32); b[:3, :] = rng.normal(size=(3, 4)).astype(np.float32)
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
+    buf = pos.tobytes()
+    doc = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}],
+        "nodes": [{"matrix": a.T.reshape(-1).tolist(), "children": [1]}, {"matrix": b.T.reshape(-1).tolist(), "mesh": 0}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0}}]}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3", "min": [0, 0, 0], "max": [1, 1, 0]}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": len(buf)}],
+        "buffers": [{"byteLength": len(buf), "uri": "data:application/octet-stream;base64," + base64.b64encode(buf).decode()}],
+    }
+    path = tmp_path / "m.gltf"
+    path.write_text(json.dumps(doc))
+    g = pkg.gltf.load_gltf(str(path))
+    # JSON round-trips f32 values exactly when they are written as the shortest repr of the double they convert to
+    ac, bc = a.T.copy(), b.T.copy()                    # columns as rows
+    want = np.zeros((4, 4), dtype=np.float32)          # want[j] = column j of a * b
+    for j in range(4):
+        col = ac[0] * bc[j][0]
+        col = col + ac[1] * bc[j][1]
+        col = col + ac[2] * bc[j][2]
+        col = col + ac[3] * bc[j][3]
+        want[j] = col
+    got = np.asarray(g.instances[0][1], dtype=np.float32)      # row-major
+    assert np.array_equal(got.T.view(np.uint32), want.view(np.uint32))
