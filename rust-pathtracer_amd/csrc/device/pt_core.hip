@@ -1416,6 +1416,22 @@ static bool repack_bvh(const PtxBvh8& bvh, std::vector<NodeRec>& out, uint32_t* 
             }
         }
     }
+    // The collapse is only equivalent when every internal child's box contains the boxes of that child's own children
+    // (exactly, as min/max unions do: the reference's builder, any sane builder).  A host tree that breaks this keeps
+    // its faithful records for every kernel: the reference's walk of it is then the only definition of a hit.
+    for (uint32_t i = 0; i < n; ++i) {
+        const PtxBvh8Node& nd = bvh.nodes[i];
+        for (int sl = 0; sl < 8; ++sl) {
+            if (!(nd.valid_mask & (1u << sl)) || (nd.children[sl] & LEAF_FLAG)) continue;
+            const PtxBvh8Node& cn = bvh.nodes[nd.children[sl]];
+            for (int t = 0; t < 8; ++t) {
+                if (!(cn.valid_mask & (1u << t))) continue;
+                const bool inside = nd.min_x[sl] <= cn.min_x[t] && nd.min_y[sl] <= cn.min_y[t] && nd.min_z[sl] <= cn.min_z[t] &&
+                                    nd.max_x[sl] >= cn.max_x[t] && nd.max_y[sl] >= cn.max_y[t] && nd.max_z[sl] >= cn.max_z[t];
+                if (!inside) return true;      // faithful roots everywhere (set above)
+            }
+        }
+    }
     if (ray_width > 1u && !repack_wide(bvh, count, out, ray_width, root_ray)) return false;
     if (packet_width > 1u) {
         if (packet_width == ray_width) *root_packet = *root_ray;

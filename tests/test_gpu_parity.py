@@ -678,3 +678,99 @@ def test_full_size_properties(pkg, loop, scenes):
         loop.set_partition(0, 1)
     own = cp > 0
     assert abs(own.mean() - 0.5) < 0.01 and np.array_equal(bits(sp[own]), bits(s1[own])) and (sp[~own] == 0).all()
+
+
+def test_upload_rejects_malformed_acceleration_structures(pkg):
+    """`ptx_upload_scene` validates what the kernels will chase: child words in range, leaf ranges in range, and the node
+    graph a TREE (a cycle would never end on the GPU; the collapse at upload walks it too).  Nothing is launched."""
+    lp = pkg.HipRenderLoop(0)
+    dt = np.dtype([("box", np.float32, (6, 8)), ("children", np.uint32, 8), ("valid", np.uint8), ("pad", np.uint8, 31)])
+
+    def nodes_of(bvh):
+        return np.ctypeslib.as_array(C.cast(bvh.nodes, C.POINTER(C.c_uint8)), shape=(int(bvh.n_nodes) * 256,)).view(dt)
+
+    def corrupt(mutate, what):
+        sc = pkg.Scene.procedural("sponza_like", 1, 0.05, 0)
+        mutate(sc.desc.contents)
+        with pytest.raises(pkg.RenderCoreError, match="PTX_ERR_INVALID"):
+            lp._bind(sc, None)
+        assert lp._scene is None or lp._scene is not sc, what
+
+    def internal_slot(nodes):
+        for i in range(len(nodes)):
+            for s in range(8):
+                if nodes[i]["valid"] >> s & 1 and not nodes[i]["children"][s] & 0x80000000:
+                    return i, s
+        raise AssertionError("no internal child")
+
+    def cycle(d):
+        n = nodes_of(d.meshes[0].bvh)
+        i, s = internal_slot(n)
+        n[i]["children"][s] = 0                     # a child pointing back at the root
+    corrupt(cycle, "cycle")
+
+    def shared_subtree(d):
+        n = nodes_of(d.tlas)
+        i, s = internal_slot(n)
+        j, t = next((a, b) for a in range(len(n)) for b in range(8)
+                    if (a, b) != (i, s) and n[a]["valid"] >> b & 1 and not n[a]["children"][b] & 0x80000000)
+        n[j]["children"][t] = n[i]["children"][s]   # two parents for one node: a DAG, not a tree
+    corrupt(shared_subtree, "dag")
+
+    def out_of_range_child(d):
+        n = nodes_of(d.tlas)
+        i, s = internal_slot(n)
+        n[i]["children"][s] = int(d.tlas.n_nodes)
+    corrupt(out_of_range_child, "child index")
+
+    def leaf_past_the_end(d):
+        n = nodes_of(d.meshes[0].bvh)
+        i = next(a for a in range(len(n)) if any(n[a]["valid"] >> b & 1 and n[a]["children"][b] & 0x80000000 for b in range(8)))
+        s = next(b for b in range(8) if n[i]["valid"] >> b & 1 and n[i]["children"][b] & 0x80000000)
+        n[i]["children"][s] = 0x80000000 | (3 << 24) | (int(d.meshes[0].bvh.n_primitive_indices) - 1)
+    corrupt(leaf_past_the_end, "leaf range")
+
+    def empty_node(d):
+        nodes_of(d.tlas)[0]["valid"] = 0
+    corrupt(empty_node, "empty node")
+    # and a good scene still uploads afterwards
+    good = pkg.Scene.procedural("sponza_like", 1, 0.05, 0)
+    lp._bind(good, None)
+    assert lp._scene is good
+
+
+def test_host_tree_with_loose_boxes_is_walked_as_given(pkg, oracle_det, monkeypatch):
+    """The collapsed trees are only equivalent when an internal child's box contains its own children's boxes.  A host
+    BVH that breaks this (here: every internal box of every mesh BVH shrunk by 30 %) keeps its faithful records for all
+    kernels; hits must equal the oracle's walk of the same arrays, per ray and as packets."""
+    sc = pkg.Scene.procedural("sponza_like", 2, 0.05, 1)
+    d = sc.desc.contents
+    dt = np.dtype([("box", np.float32, (6, 8)), ("children", np.uint32, 8), ("valid", np.uint8), ("pad", np.uint8, 31)])
+    shrunk = 0
+    for m in range(d.n_meshes):
+        bvh = d.meshes[m].bvh
+        nodes = np.ctypeslib.as_array(C.cast(bvh.nodes, C.POINTER(C.c_uint8)), shape=(int(bvh.n_nodes) * 256,)).view(dt)
+        for i in range(len(nodes)):
+            for s in range(8):
+                if nodes[i]["valid"] >> s & 1 and not nodes[i]["children"][s] & 0x80000000:
+                    b = nodes[i]["box"][:, s]           # min_x max_x min_y max_y min_z max_z
+                    for a in range(3):
+                        c, h = 0.5 * (b[2 * a] + b[2 * a + 1]), 0.35 * (b[2 * a + 1] - b[2 * a])
+                        b[2 * a], b[2 * a + 1] = c - h, c + h
+                    shrunk += 1
+    assert shrunk > 100
+    w, h = 160, 90
+    cam = sc.default_camera(w / h)
+    osc = oracle_det.scene(sc)
+    rays = osc.primary_rays(cam, w, h, 0)
+    want, want_any = osc.trace_closest(rays), osc.trace_any(rays)
+    lp = pkg.HipRenderLoop(0)
+    monkeypatch.setenv("PTX_PACKET_BATCH", "1")
+    lpk = pkg.HipRenderLoop(0)
+    for loop_ in (lp, lpk):
+        assert np.array_equal(loop_.trace_closest(sc, rays).view(np.uint8), want.view(np.uint8))
+        assert np.array_equal(loop_.trace_any(sc, rays), want_any)
+    assert np.array_equal(bits(lp.render_pass(sc, cam, pkg.PathTracer(8), w, h, 1)), bits(osc.render_pass(cam, w, h, 1, 8)))
+    # the shrunk boxes do lose hits: this tree is not the one the builder made
+    good = pkg.Scene.procedural("sponza_like", 2, 0.05, 1)
+    assert not np.array_equal(oracle_det.scene(good).trace_closest(rays)["tri_idx"], want["tri_idx"])
