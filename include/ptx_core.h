@@ -418,7 +418,10 @@ typedef struct PtxDebugStats {
     uint32_t trace_stack_high_water;
     uint32_t packet_stack_high_water;
     uint64_t packet_redo_rays;
-    uint32_t lds_stack_entries, packet_lds_entries, packet_capacity, _pad;
+    uint32_t lds_stack_entries, packet_lds_entries, packet_capacity;
+    float max_leaf_undershoot;   /* counted kernels: largest (t_enter(leaf box) - t) / t over all triangle hits computed */
+    uint32_t bound_forwarding;   /* 1 = closest-hit rays take the world closest_t into instances, 0 = off for this scene */
+    uint32_t _pad;
 } PtxDebugStats;
 int32_t ptx_get_debug_stats(PtxContext* ctx, PtxDebugStats* out);
 

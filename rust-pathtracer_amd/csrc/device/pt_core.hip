@@ -153,6 +153,10 @@ PT_DEV void flush_lane_cnt(DevCounters* dc, const LaneCnt& lc, uint32_t rays, bo
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor(hw, off); hw = o > hw ? o : hw; }
       if ((threadIdx.x & 63u) == 0u && hw) atomicMax(&dc->dbg[0], hw); }
+    { float us = lc.undershoot;      // >= 0: non-negative floats order like their bit patterns
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(us, off); us = o > us ? o : us; }
+      if ((threadIdx.x & 63u) == 0u && us > 0.0f) atomicMax(&dc->dbg[4], __float_as_uint(us)); }
     if (any) {
         wave_add(&dc->v[C_ANY_NODE_VISITS], lc.node_visits);
         wave_add(&dc->v[C_ANY_NODE_CHILDREN], lc.node_children);
@@ -191,7 +195,7 @@ template <bool ANY, bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
                                                              uint8_t* out_any, uint32_t* work, uint2* ovf, DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f};
     uint32_t nrays = 0, e = 0;
     BatchSrc src{rays};
     BatchSink<ANY> sink{out_hits, out_any};
@@ -269,7 +273,7 @@ template <bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S, PathArrays P, const uint32_t* q, const uint32_t* q_walk, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f};
     uint32_t nrays = 0, e = 0;
     const uint32_t n_active = ctr->n_active, n_walk = ctr->n_walk;
     ExtendSrc src{P, q, n_active, q_walk};
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_extend_packet(Sc
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend_redo(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
                                                              DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f};
     uint32_t nrays = 0, e = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
@@ -346,7 +350,7 @@ template <bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_shadow(SceneDev S, PathArrays P, const uint32_t* qs, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f};
     uint32_t nrays = 0, e = 0;
     ShadowSrc src{S, P, qs};
     ShadowSink sink{P};
@@ -1361,8 +1365,9 @@ constexpr uint32_t REPACK_MAX_DEPTH = 512;
 // of the collapsed trees the per-ray and the packet kernels walk (width <= 1: no collapse, the faithful root).
 static bool repack_wide(const PtxBvh8& bvh, const std::vector<uint32_t>& count, std::vector<NodeRec>& out, uint32_t width, uint32_t* root_wide);
 static bool repack_bvh(const PtxBvh8& bvh, std::vector<NodeRec>& out, uint32_t* root_faithful, uint32_t ray_width, uint32_t* root_ray,
-                       uint32_t packet_width, uint32_t* root_packet) {
+                       uint32_t packet_width, uint32_t* root_packet, bool* nests = nullptr) {
     const size_t first = out.size();
+    if (nests) *nests = false;
     const uint32_t n = bvh.n_nodes;
     if (n == 0 || n > NODE_INDEX_MASK / 2) return false;
     std::vector<uint32_t> unit(n), count(n);
@@ -1432,6 +1437,7 @@ static bool repack_bvh(const PtxBvh8& bvh, std::vector<NodeRec>& out, uint32_t* 
             }
         }
     }
+    if (nests) *nests = true;
     if (ray_width > 1u && !repack_wide(bvh, count, out, ray_width, root_ray)) return false;
     if (packet_width > 1u) {
         if (packet_width == ray_width) *root_packet = *root_ray;
@@ -1485,6 +1491,32 @@ static bool repack_wide(const PtxBvh8& bvh, const std::vector<uint32_t>& count, 
             const size_t prec = patch / 64, k = patch % 64;
             float f; std::memcpy(&f, &my_word, 4);
             out[prec + k / 4].c[2 * (k % 4) + 1].z = f;
+        }
+    }
+    return true;
+}
+
+// forwarded_bound (pt_traverse.h) culls a mesh node by its entry distance before any of its triangles has been seen,
+// which presumes that a triangle lies inside the boxes above it: every leaf box must contain its triangles' vertices
+// and so must the Blas box (the mesh bounds: the unpadded vertex extent, shape/triangle_mesh.rs:23,54-59).  True of the
+// reference's builder (leaf boxes are unions of triangle boxes padded by 1e-5: shape/triangle_mesh.rs:25-38); a host
+// tree that breaks it is walked without forwarding.
+static bool mesh_boxes_hold_geometry(const PtxMesh& m) {
+    const PtxBvh8& bvh = m.bvh;
+    for (uint32_t i = 0; i < bvh.n_nodes; ++i) {
+        const PtxBvh8Node& nd = bvh.nodes[i];
+        for (int s = 0; s < 8; ++s) {
+            if (!(nd.valid_mask & (1u << s))) continue;
+            const float lo[3] = {nd.min_x[s], nd.min_y[s], nd.min_z[s]}, hi[3] = {nd.max_x[s], nd.max_y[s], nd.max_z[s]};
+            if (!(nd.children[s] & LEAF_FLAG)) continue;
+            const uint32_t start = nd.children[s] & PRIM_START_MASK, cnt = ((nd.children[s] >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
+            for (uint32_t k = start; k < start + cnt; ++k) {
+                const uint32_t* tri = &m.indices[3 * (size_t)bvh.primitive_indices[k]];
+                for (int v = 0; v < 3; ++v) {
+                    const float* p = &m.positions[3 * (size_t)tri[v]];
+                    for (int a = 0; a < 3; ++a) if (!(lo[a] <= p[a] && p[a] <= hi[a] && m.bounds_min[a] <= p[a] && p[a] <= m.bounds_max[a])) return false;
+                }
+            }
         }
     }
     return true;
@@ -1837,6 +1869,7 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
             if (sc->tlas.primitive_indices[i] >= sc->n_instances) return fail(ctx, PTX_ERR_INVALID, "TLAS primitive index out of range");
     }
     const uint32_t n_tlas_records = (uint32_t)nodes.size();
+    bool forward_ok = true;      // forwarded_bound needs triangles inside the boxes above them, in every mesh
     for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
         const PtxMesh& m = sc->meshes[mi];
         if (!m.positions || !m.indices || !m.n_triangles) return fail(ctx, PTX_ERR_INVALID, "mesh without geometry");
@@ -1857,11 +1890,14 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
         r.node_base = (uint32_t)nodes.size();
         r.tri_base = (uint32_t)tris.size();
         if (r.node_base > NODE_INDEX_MASK) return fail(ctx, PTX_ERR_UNSUPPORTED, "more than 2^29 node records");
-        if (!repack_bvh(m.bvh, nodes, &mesh_root_word[mi], ctx->ray_width, &mesh_root_word_ray[mi], ctx->packet_width, &mesh_root_word_packet[mi]))
+        bool nests = false;
+        if (!repack_bvh(m.bvh, nodes, &mesh_root_word[mi], ctx->ray_width, &mesh_root_word_ray[mi], ctx->packet_width, &mesh_root_word_packet[mi], &nests))
             return fail(ctx, PTX_ERR_INVALID, "mesh BVH is empty, not a tree or has a child word out of range");
+        for (uint32_t s = 0; s < m.bvh.n_primitive_indices; ++s)
+            if (m.bvh.primitive_indices[s] >= m.n_triangles) return fail(ctx, PTX_ERR_INVALID, "mesh BVH primitive index out of range");
+        if (!nests || !mesh_boxes_hold_geometry(m)) forward_ok = false;
         for (uint32_t s = 0; s < m.bvh.n_primitive_indices; ++s) {
             const uint32_t t = m.bvh.primitive_indices[s];
-            if (t >= m.n_triangles) return fail(ctx, PTX_ERR_INVALID, "mesh BVH primitive index out of range");
             const uint32_t* tri = &m.indices[3 * (size_t)t];
             const float* p0 = &m.positions[3 * (size_t)tri[0]]; const float* p1 = &m.positions[3 * (size_t)tri[1]]; const float* p2 = &m.positions[3 * (size_t)tri[2]];
             TriRec tr;
@@ -2000,6 +2036,47 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
     S.tlas_root_word_ray = tlas_root_word_ray;
     S.tlas_root_word_packet = tlas_root_word_packet;
     S.has_sss = has_sss ? 1u : 0u;
+    {
+        // forwarded_bound's constants (pt_traverse.h).  For a ray o + t d and an instance with matrices M, V (= the f32
+        // inverse the host supplies), the reference computes o_l = fl(V o), d_l = fl(V d) and, for a local hit at t,
+        // t_w = fl(((M (o_l + t d_l)) - o) . d / d.d).  In exact arithmetic on those f32 values
+        //   t_w - t = ((R o_1 + M do) . d + t (R d + M dd) . d) / d.d,   R = M V - I,  |do| <= g |V| |o_1|,  |dd| <= g |V| |d|,
+        // (o_1 = (o, 1)) and evaluating t_w in f32 adds a few more ulps of the same magnitudes.  With the abs-matrix
+        // norms below, |t_w - t| <= (lin |o|_1 + tr) / |d| + t lin, lin = 64 eps |M||V| + 4 |R|: 64 ulps cover the
+        // ~20 roundings on any path with room to spare.  The relative part must stay far below the 2^-5 the bound adds.
+        const double eps = 5.9604644775390625e-08;
+        double lin = 0.0, tr = 0.0;
+        bool ok = forward_ok;
+        for (uint32_t i = 0; i < sc->n_instances; ++i) {
+            const float* M = sc->instances[i].transform;            // column-major
+            const float* V = sc->instances[i].inverse_transform;
+            for (int r = 0; r < 3; ++r) {
+                double a_lin = 0.0, a_t = std::fabs((double)M[12 + r]), r_lin = 0.0, r_t = (double)M[12 + r];
+                for (int c = 0; c < 3; ++c) {
+                    double prod = 0.0;
+                    for (int k = 0; k < 3; ++k) {
+                        a_lin += std::fabs((double)M[4 * k + r]) * std::fabs((double)V[4 * c + k]);
+                        prod += (double)M[4 * k + r] * (double)V[4 * c + k];
+                    }
+                    r_lin += std::fabs(prod - (r == c ? 1.0 : 0.0));
+                }
+                for (int k = 0; k < 3; ++k) {
+                    a_t += std::fabs((double)M[4 * k + r]) * std::fabs((double)V[12 + k]);
+                    r_t += (double)M[4 * k + r] * (double)V[12 + k];
+                }
+                const double l = 64.0 * eps * a_lin + 4.0 * r_lin, t = 64.0 * eps * a_t + 4.0 * std::fabs(r_t);
+                if (!(l == l) || !(t == t)) ok = false;
+                lin = l > lin ? l : lin;
+                tr = t > tr ? t : tr;
+            }
+            // the fourth row must be (0,0,0,1): transform_point3 ignores it
+        }
+        const char* off = std::getenv("PTX_NO_FORWARD");
+        S.fwd_on = (ok && lin <= 1.0 / 256.0 && tr < 1e30 && !(off && off[0] == '1')) ? 1u : 0u;
+        // measurement only: PTX_COUNT_FORWARD=1 lets the counted kernels forward too (their counts are then this library's, not the reference's)
+        if (S.fwd_on) { const char* cf = std::getenv("PTX_COUNT_FORWARD"); if (cf && cf[0] == '1') S.fwd_on = 2u; }
+        S.fwd_lin = (float)(lin * 1.0000002); S.fwd_t = (float)(tr * 1.0000002);
+    }
     // shading triangles: built on the device from the pools just uploaded, one launch per mesh
     {
         ShadeTri* d_shade = nullptr;
@@ -2548,8 +2625,11 @@ int32_t ptx_get_debug_stats(PtxContext* ctx, PtxDebugStats* out) {
     REQUIRE_CTX();
     if (!out) return fail(ctx, PTX_ERR_INVALID, "null output");
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    unsigned int dbg[4];
+    unsigned int dbg[6];
     HIPCHK(hipMemcpy(dbg, ctx->d_counters->dbg, sizeof(dbg), hipMemcpyDeviceToHost));
+    std::memcpy(&out->max_leaf_undershoot, &dbg[4], 4);
+    out->bound_forwarding = ctx->has_scene ? ctx->S.fwd_on : 0u;
+    out->_pad = 0;
     out->trace_stack_high_water = dbg[0];
     out->packet_stack_high_water = dbg[1];
     out->packet_redo_rays = (uint64_t)dbg[2] | ((uint64_t)dbg[3] << 32);

@@ -149,7 +149,9 @@ PT_DEV uint2 st_read(const StackRef& s, int i) {
     return v;
 }
 
-struct LaneCnt { uint32_t node_visits, node_children, prim_reads, tri_tests, inst_entries, inst_hits, stack_hw; };   // stack_hw: deepest stack this lane reached (counted kernels)
+// stack_hw: deepest stack this lane reached; undershoot: largest (t_enter(leaf box) - t) / t over the triangle hits this
+// lane computed (how far a hit can lie in front of the boxes above it: forwarded_bound tolerates 2^-5) — counted kernels
+struct LaneCnt { uint32_t node_visits, node_children, prim_reads, tri_tests, inst_entries, inst_hits, stack_hw; float undershoot; };
 
 PT_DEV V3 xf_point(const float4 a, const float4 b, const float4 c, V3 p) {
     // Mat4::transform_point3: ((x_axis*x + y_axis*y) + z_axis*z) + w_axis, packed columns
@@ -193,6 +195,19 @@ PT_DEV bool ray_needs_exact(V3 o, V3 inv) {
     return !(finitef(inv.x) && finitef(inv.y) && finitef(inv.z) && finitef(o.x) && finitef(o.y) && finitef(o.z));
 }
 
+// The bound a closest-hit ray takes into an instance (see "Forwarding the world bound" in DESIGN.md).  The reference
+// searches an instance's mesh with t_max = +inf and compares the winner's re-derived world t with the world closest_t
+// afterwards (accel/mod.rs:123-137).  Local t and world t are the same parameter up to rounding, so a local hit at
+// t >= B, B = closest_t * (1 + 2^-5) + the certified rounding bound of the round trip, is rejected by that comparison
+// whatever it is: the mesh level may start from closest_t = B instead of +inf.  Not for any-hit rays (hit_any ignores
+// the world t_max inside an instance: accel/mod.rs:141-146), NaN-slab rays, the counted kernels, or directions far
+// from unit length (the bound's constants assume 0.5 <= |d|^2 <= 2).
+PT_DEV float forwarded_bound(const SceneDev& S, V3 o, V3 d, float ct) {
+    const float dd = dot(d, d);
+    const float b = ct * 1.03125f + 1.5f * (S.fwd_lin * ((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + S.fwd_t);
+    return (S.fwd_on != 0u && dd >= 0.5f && dd <= 2.0f) ? b : PT_INF;
+}
+
 enum : uint32_t { ACT_IDLE = 0, ACT_NODE = 1, ACT_TRI = 2, ACT_ENTER = 3, ACT_EXIT = 4, ACT_POP = 5, ACT_DONE = 6 };
 
 // Per-lane traversal state.  The world ray is not kept while a lane is inside an instance: it is re-read from the
@@ -209,6 +224,7 @@ struct Traverser {
     uint32_t pw;               // NODE: child word; TRI: next TriRec; ENTER: TLAS leaf word; EXIT: marker word
     uint32_t tri_cnt;          // TRI: triangles left in the leaf
     bool in_mesh, found, exact;
+    float leaf_dist;           // counted kernels: entry distance of the leaf whose triangles are being tested
 
     // which tree the current level is walked in: the faithful one for NaN-slab rays and for the counted kernels
     PT_DEV bool faithful() const { return CNT || exact; }
@@ -239,6 +255,7 @@ struct Traverser {
                 if (e.y == NEG_INF_BITS) act = ACT_EXIT;       // the marker: mesh level drained
                 else if (e.x & LEAF_FLAG) {
                     act = ACT_TRI;
+                    if (CNT) leaf_dist = __uint_as_float(e.y);
                     pw = tri_base + (e.x & PRIM_START_MASK);
                     tri_cnt = ((e.x >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
                 } else act = ACT_NODE;
@@ -317,6 +334,7 @@ struct Traverser {
         const bool hit = !(fabsf(a) < 1e-8f) && (u >= 0.0f && u <= 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
                          (t >= tmin && t <= PT_INF);   // local ray: t_max = +inf
         if (hit) {
+            if (CNT) { const float us = (leaf_dist - t) / t; lc.undershoot = us > lc.undershoot ? us : lc.undershoot; }
             if (ANY) { found = true; act = ACT_DONE; return; }
             if (t < ct) { ct = t; m_tri = __float_as_uint(tc.y); m_u = u; m_v = v; }
         }
@@ -343,7 +361,8 @@ struct Traverser {
         bool bhit;
         if (__ballot(lexact) != 0ull) bhit = box_test<true>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
         else bhit = box_test<false>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
-        if (!bhit || (!ANY && tb_enter >= PT_INF)) { act = ACT_POP; return; }
+        const float bound = (ANY || exact || lexact || (CNT && S.fwd_on < 2u)) ? PT_INF : forwarded_bound(S, o, d, ct);
+        if (!bhit || (!ANY && tb_enter >= bound)) { act = ACT_POP; return; }
         if (CNT) lc.prim_reads++;   // the Blas leaf's own primitive index
         // park the world level under a marker and descend into the mesh BVH
         // (TriangleMesh::hit: closest_t = local t_max = +inf; root popped with dist 0)
@@ -352,7 +371,7 @@ struct Traverser {
         st_write(st, sp++, inst_idx | (exact ? MARK_EXACT : 0u), NEG_INF_BITS);
         if (CNT) lc.stack_hw = (uint32_t)sp > lc.stack_hw ? (uint32_t)sp : lc.stack_hw;
         in_mesh = true;
-        ct = PT_INF;
+        ct = bound;
         o = lo; d = ld; inv = linv;
         exact = lexact;
         tri_base = __float_as_uint(b1.w);
@@ -410,6 +429,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
     tv.exact = false; tv.in_mesh = false; tv.found = false;
     tv.sp = 0; tv.pw = 0; tv.tri_cnt = 0; tv.tri_base = 0; tv.m_tri = PTX_MISS; tv.m_u = 0.0f; tv.m_v = 0.0f;
     tv.ct = 0.0f; tv.o = v3(0.0f, 0.0f, 0.0f); tv.d = tv.o; tv.inv = tv.o;
+    tv.leaf_dist = 0.0f;
     uint32_t my = 0;
     // Idle lanes claim queue entries with one wave-aggregated atomic as soon as REFILL_MIN_IDLE of them have
     // gathered.  (Claiming a chunk ahead of need was measured and rejected: a launch lasts only ~16 ray lifetimes,
@@ -688,7 +708,8 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                     bool bhit;
                     if (__ballot(act && lexact) != 0ull) bhit = box_test<true>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
                     else bhit = box_test<false>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
-                    const bool enter = act && bhit && (ANY || !(tb_enter >= PT_INF));
+                    const float bound = (ANY || exact || lexact) ? PT_INF : forwarded_bound(S, o, d, ct);
+                    const bool enter = act && bhit && (ANY || !(tb_enter >= bound));
                     const unsigned long long em = __ballot(enter);
                     if (em == 0ull) continue;
                     // park the world level under a marker entry and descend into the mesh BVH
@@ -700,7 +721,7 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                     marker_sp = sp;
                     pk_write(st, sp++, 0u, 0u);
                     pk_write(st, sp++, (__ballot(enter && lexact) != 0ull ? g_root_faithful : g_root_packet)[start], enter ? 0u : POS_INF_BITS);
-                    if (enter) { o = lo; d = ld; inv = linv; exact = lexact; ct = PT_INF; m_tri = PTX_MISS; }
+                    if (enter) { o = lo; d = ld; inv = linv; exact = lexact; ct = bound; m_tri = PTX_MISS; }
                     in_mesh = true;
                 }
             } else {

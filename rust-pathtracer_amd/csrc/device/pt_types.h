@@ -135,6 +135,9 @@ struct SceneDev {
     uint32_t tlas_root_word_ray;   // TLAS the per-ray kernels walk (== tlas_root_word unless PTX_WIDE_RAY_BVH asks for a collapse)
     uint32_t tlas_root_word_packet;   // wide TLAS of the packet kernels (== tlas_root_word when the collapse is off)
     uint32_t has_sss;
+    // forwarded_bound (pt_traverse.h): rounding bound of world -> local -> world, certified per scene at upload
+    uint32_t fwd_on;
+    float fwd_lin, fwd_t;
 };
 
 struct CameraDev {
@@ -147,8 +150,8 @@ struct CameraDev {
 struct DevCounters {
     unsigned long long v[sizeof(PtxCounters) / 8];
     // PtxDebugStats (not part of PtxCounters): [0] deepest per-ray stack (counted kernels), [1] deepest packet stack,
-    // [2..3] rays handed from overflowed packets to k_extend_redo (u64)
-    unsigned int dbg[4];
+    // [2..3] rays handed from overflowed packets to k_extend_redo (u64), [4] largest leaf undershoot (f32 bits, counted kernels)
+    unsigned int dbg[6];
 };
 enum CounterId {
     C_RAYS_CLOSEST, C_RAYS_ANY, C_NODE_VISITS, C_NODE_CHILDREN, C_PRIM_INDEX_READS, C_TRI_TESTS,

@@ -285,3 +285,41 @@ def test_zero_and_oversized_bounce_limits(pkg, loop, oracle_det):
     assert (c == 3).all() and (s == 0).all()
     with pytest.raises(pkg.RenderCoreError):
         loop.render_pass(sc, cam, pkg.PathTracer(256), w, h, 0)
+
+
+def test_forwarded_bound_changes_no_hit_and_hits_sit_inside_their_boxes(pkg, loop, oracle_det, full_scenes, monkeypatch):
+    """Closest-hit rays take the world closest_t (x 1.03125 + the certified rounding bound of world -> local -> world)
+    into an instance instead of the reference's +inf (`forwarded_bound`, csrc/device/pt_traverse.h; DESIGN.md says why
+    the comparison after the instance rejects everything the tighter start skips).  The argument presumes that a
+    triangle hit does not lie far in front of the boxes above it; the counted kernels measure exactly that
+    (`max_leaf_undershoot`: the bound tolerates 2^-5, here it must stay below 2^-9), and with forwarding switched off
+    (PTX_NO_FORWARD=1, read at upload) the same rays must give the same bytes."""
+    abi = pkg._abi
+    monkeypatch.setenv("PTX_NO_FORWARD", "1")
+    lp_off = pkg.HipRenderLoop(0)
+    for name in FULL:
+        sc = full_scenes(name)
+        w, h = 400, 225
+        cam = sc.default_camera(w / h)
+        osc = oracle_det.scene(sc)
+        prim = osc.primary_rays(cam, w, h, 9)
+        rays = np.concatenate([prim, secondary_rays(abi, osc, prim, osc.trace_closest(prim), 21)])
+        want = osc.trace_closest(rays)
+        off = lp_off.trace_closest(sc, rays)                 # uploads with the switch set
+        assert lp_off.debug_stats()["bound_forwarding"] == 0
+        monkeypatch.delenv("PTX_NO_FORWARD")
+        loop._scene = None                                   # a fresh upload without the switch
+        on = loop.trace_closest(sc, rays)
+        assert loop.debug_stats()["bound_forwarding"] == 1, name
+        monkeypatch.setenv("PTX_NO_FORWARD", "1")
+        assert np.array_equal(on.view(np.uint8), want.view(np.uint8)) and np.array_equal(off.view(np.uint8), want.view(np.uint8)), name
+        loop.set_counting(True)
+        loop.reset_counters()
+        loop.trace_closest(sc, rays)
+        loop.trace_any(sc, rays)
+        dbg = loop.debug_stats()
+        loop.set_counting(False)
+        print(f"\n[{name}] {len(rays)} rays: largest (t_enter(leaf) - t) / t over all triangle hits = {dbg['max_leaf_undershoot']:.3e}")
+        assert 0.0 <= dbg["max_leaf_undershoot"] < 2.0 ** -9, (name, dbg)
+        img = osc.render_pass(cam, 160, 90, 4, FULL[name][1])
+        assert np.array_equal(bits(loop.render_pass(sc, cam, pkg.PathTracer(FULL[name][1]), 160, 90, 4)), bits(img)), name

@@ -774,3 +774,123 @@ def test_host_tree_with_loose_boxes_is_walked_as_given(pkg, oracle_det, monkeypa
     # the shrunk boxes do lose hits: this tree is not the one the builder made
     good = pkg.Scene.procedural("sponza_like", 2, 0.05, 1)
     assert not np.array_equal(oracle_det.scene(good).trace_closest(rays)["tri_idx"], want["tri_idx"])
+
+
+def _uv_sphere(n_lat=10, n_lon=16):
+    pos = [(0.0, 1.0, 0.0)]
+    for i in range(1, n_lat):
+        th = np.pi * i / n_lat
+        for j in range(n_lon):
+            ph = 2 * np.pi * j / n_lon
+            pos.append((np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)))
+    pos.append((0.0, -1.0, 0.0))
+    idx = []
+    ring = lambda i, j: 1 + (i - 1) * n_lon + j % n_lon
+    for j in range(n_lon):
+        idx.append((0, ring(1, j), ring(1, j + 1)))
+        idx.append((len(pos) - 1, ring(n_lat - 1, j + 1), ring(n_lat - 1, j)))
+    for i in range(1, n_lat - 1):
+        for j in range(n_lon):
+            idx.append((ring(i, j), ring(i + 1, j), ring(i + 1, j + 1)))
+            idx.append((ring(i, j), ring(i + 1, j + 1), ring(i, j + 1)))
+    return np.array(pos, dtype=np.float32), np.array(idx, dtype=np.uint32)
+
+
+def _rot(axis, angle):
+    a = np.asarray(axis, dtype=np.float64)
+    a /= np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * K @ K
+
+
+def _affine(lin, t):
+    m = np.eye(4)
+    m[:3, :3], m[:3, 3] = lin, t
+    return m
+
+
+def _rays_at_instances(abi, pos, transforms, seed, per_instance=400):
+    """Rays aimed at points of every instance's surface: infinite ones, segments that end within a few percent of the
+    surface (either side: the band a forwarded bound must not cut into), and directions far from unit length."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for m in transforms:
+        world = pos.astype(np.float64) @ m[:3, :3].T + m[:3, 3]
+        size = np.linalg.norm(world.max(0) - world.min(0))
+        target = world[rng.integers(0, len(world), per_instance)] * (1 - 0.2 * rng.uniform(size=(per_instance, 1))) + \
+            0.2 * rng.uniform(size=(per_instance, 1)) * world.mean(0)
+        origin = target + rng.normal(size=(per_instance, 3)) * size * rng.choice([0.6, 2.0, 8.0], size=(per_instance, 1))
+        d = target - origin
+        dist = np.linalg.norm(d, axis=1, keepdims=True)
+        d /= dist
+        scale = rng.choice([1.0, 1.0, 1.0, 0.1, 7.0], size=(per_instance, 1))          # |d| = 1, 0.1 or 7
+        r = np.zeros(per_instance, dtype=abi.ray_dtype())
+        r["origin"], r["direction"] = origin.astype(np.float32), (d * scale).astype(np.float32)
+        tm = np.where(rng.uniform(size=per_instance) < 0.5, np.inf, (dist[:, 0] / scale[:, 0]) * rng.uniform(0.9, 1.1, per_instance))
+        r["t_max"] = tm.astype(np.float32)
+        out.append(r)
+    return np.concatenate(out)
+
+
+def test_forwarded_bound_with_hard_instance_transforms(pkg, loop, oracle_det, monkeypatch):
+    """`forwarded_bound` (pt_traverse.h) rests on a per-scene certified bound for the world -> local -> world round
+    trip.  Instances far from the origin, tiny, huge, anisotropic, sheared and thin — each with a twin whose surface
+    nearly coincides (offsets from one part in 10^7 to one in 10^2 of the instance's size, so that world distances of
+    different instances differ by roundings only) — must give the oracle's bytes per ray and as packets.  A scene
+    whose instance matrices are too ill-conditioned for the bound switches forwarding off by itself."""
+    abi = pkg._abi
+    pos, idx = _uv_sphere()
+    lins = [
+        (np.eye(3) * 0.01, (5000.0, -3000.0, 2000.0)),
+        (_rot((1, 2, 3), 1.1) @ np.diag([50.0, 1.0, 0.2]), (3.0, 1.0, -2.0)),
+        (np.array([[1.0, 2.0, 0.0], [0.0, 1.0, 3.0], [0.0, 0.0, 1.0]]), (-40.0, 7.0, 11.0)),
+        (np.eye(3) * 300.0, (100.0, 900.0, -250.0)),
+        (_rot((0, 1, 1), 0.4) @ np.diag([1.0, 1.0, 1e-3]), (0.0, 0.0, 0.0)),
+        (_rot((2, -1, 0.5), 2.3) @ np.diag([4.0, 0.5, 2.0]) @ _rot((0, 0, 1), 0.7), (12.0, -6.0, 30.0)),
+    ]
+    transforms = []
+    rng = np.random.default_rng(5)
+    for k, (lin, t) in enumerate(lins):
+        m = _affine(lin, t)
+        transforms.append(m)
+        size = np.linalg.norm(lin, 2)
+        for rel in (1e-7, 1e-4, 1e-2):                       # twins: nearly coincident surfaces in other instances
+            transforms.append(_affine(lin, np.asarray(t) + rng.normal(size=3) * size * rel))
+
+    def build(ts):
+        b = pkg.SceneBuilder()
+        b.add_material(pkg.default_material())
+        mesh = b.add_mesh(pos, idx)
+        order = rng.permutation(len(ts))                     # TLAS order unrelated to distance
+        for i in order:
+            b.add_instance(mesh, ts[i].astype(np.float32))
+        b.set_sky_solid(0.5, 0.6, 0.8)
+        return b.build()
+
+    sc = build(transforms)
+    osc = oracle_det.scene(sc)
+    rays = _rays_at_instances(abi, pos, transforms, 17)
+    want, want_any = osc.trace_closest(rays), osc.trace_any(rays)
+    assert (want["inst_idx"] != abi.PTX_MISS).mean() > 0.2
+    monkeypatch.setenv("PTX_PACKET_BATCH", "1")
+    lpk = pkg.HipRenderLoop(0)
+    monkeypatch.delenv("PTX_PACKET_BATCH")
+    for loop_ in (loop, lpk):
+        got = loop_.trace_closest(sc, rays)
+        assert loop_.debug_stats()["bound_forwarding"] == 1
+        bad = np.flatnonzero((got.view(np.uint8).reshape(len(rays), -1) != want.view(np.uint8).reshape(len(rays), -1)).any(axis=1))
+        assert len(bad) == 0, (len(bad), rays[bad[:3]], got[bad[:3]], want[bad[:3]])
+        assert np.array_equal(loop_.trace_any(sc, rays), want_any)
+    # coherent bundles through the twins (what the packet kernel is for)
+    cam = pkg.Camera.look_at((3.0, 1.0, 60.0), (3.0, 1.0, -2.0), 50.0, 16 / 9)
+    prim = osc.primary_rays(cam, 160, 90, 0)
+    for loop_ in (loop, lpk):
+        assert np.array_equal(loop_.trace_closest(sc, prim).view(np.uint8), osc.trace_closest(prim).view(np.uint8))
+    # an instance squeezed by 10^5 between two rotations: |M||M^-1| is ~10^5, the bound would be useless -> forwarding off
+    ill = transforms[:4] + [_affine(_rot((1, 1, 0), 0.8) @ np.diag([1.0, 1.0, 1e-5]) @ _rot((0, 1, 2), 1.3), (1.0, 2.0, 3.0))]
+    sc2 = build(ill)
+    osc2 = oracle_det.scene(sc2)
+    rays2 = _rays_at_instances(abi, pos, ill, 23, 200)
+    got2 = loop.trace_closest(sc2, rays2)
+    assert loop.debug_stats()["bound_forwarding"] == 0
+    assert np.array_equal(got2.view(np.uint8), osc2.trace_closest(rays2).view(np.uint8))
