@@ -256,6 +256,10 @@ def main():
         "frame_reference_stream_frac": round(abytes_frame / sec_per_frame / 1e9 / HBM_PEAK_GBS, 5),   # reference byte stream / 8 TB/s: can exceed 1 (caches)
         "kernel_ms_per_frame": {k: round(tim[k] / args.steps, 3) for k in
                                 ("raygen_ms", "packet_ms", "extend_ms", "shade_ms", "shadow_ms", "accumulate_ms")},
+        "kernel_ms_note": ("HIP-event time per kernel class. shadow_ms and accumulate_ms are launched on the library's side stream beside the next "
+                           "iteration's k_extend (PTX_OVERLAP_SHADOW, default on) and include the time they wait for wave slots behind it: "
+                           "the classes overlap and do not sum to the frame. PTX_OVERLAP_SHADOW=0 (what profiles/ are taken with) serialises them."
+                           if os.environ.get("PTX_OVERLAP_SHADOW", "1") != "0" else "HIP-event time per kernel class, one stream (PTX_OVERLAP_SHADOW=0)"),
         "scene_build_s": round(build_s, 2),
         "verify": verify,
         "roofline": roofline,

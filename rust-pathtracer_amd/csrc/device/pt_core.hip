@@ -1231,6 +1231,11 @@ struct PtxContext {
     uint64_t max_paths_in_flight = 128ull << 20;  // ptx_fb_render_passes traces up to this many path slots (260 B each: 35 GB of the 288) per wavefront batch (PTX_PATHS_IN_FLIGHT)
     int device = 0;
     hipStream_t stream = nullptr;
+    // the any-hit launch of iteration i and its k_finalize run here, beside iteration i + 1's closest-hit launch on
+    // `stream` (run_paths); ev_main / ev_side order the two streams
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    bool overlap_shadow = true;
     std::string err;
 
     bool has_scene = false, has_camera = false;
@@ -1247,6 +1252,7 @@ struct PtxContext {
     int packet_capacity = PACKET_LDS + OVF_STACK;   // PTX_PACKET_CAPACITY (tests): smaller packet stacks, to exercise the redo path
     IterCtr* ctrs = nullptr;
     uint2* ovf = nullptr;
+    uint2* ovf_side = nullptr;      // stack strips of the launches on side_stream
     uint32_t* d_err = nullptr;
     DevCounters* d_counters = nullptr;
     uint32_t* h_pinned = nullptr;    // 64 u32 of pinned readback scratch
@@ -1272,7 +1278,7 @@ struct PtxContext {
     uint32_t adaptive_batch = 32;   // adaptive passes traced together by ptx_fb_adaptive_passes (PTX_ADAPTIVE_BATCH)
     bool adaptive_batch_auto = true;   // no PTX_ADAPTIVE_BATCH: start at 32 and double (up to 256) while >= 90 % of a batch's speculative samples were kept
     bool counting = false, profiling = false;
-    struct Ev { hipEvent_t a, b; int cls; };
+    struct Ev { hipEvent_t a, b; int cls; hipStream_t stream; };
     std::vector<Ev> events;
     PtxTimings timings{};
 };
@@ -1597,18 +1603,19 @@ constexpr uint32_t SSS_POLL_EVERY = 8;
 enum { CLS_RAYGEN = 0, CLS_EXTEND, CLS_SHADE, CLS_SHADOW, CLS_ACCUM, CLS_OTHER, CLS_PACKET, CLS_WALK };
 struct ScopedEvent {
     PtxContext* ctx; int idx = -1;
-    ScopedEvent(PtxContext* c, int cls) : ctx(c) {
+    ScopedEvent(PtxContext* c, int cls, hipStream_t on = nullptr) : ctx(c) {
         if (!c->profiling) return;
-        PtxContext::Ev e; e.cls = cls;
+        PtxContext::Ev e; e.cls = cls; e.stream = on ? on : c->stream;
         if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
-        (void)hipEventRecord(e.a, c->stream);
+        (void)hipEventRecord(e.a, e.stream);
         c->events.push_back(e); idx = (int)c->events.size() - 1;
     }
-    ~ScopedEvent() { if (idx >= 0) (void)hipEventRecord(ctx->events[idx].b, ctx->stream); }
+    ~ScopedEvent() { if (idx >= 0) (void)hipEventRecord(ctx->events[idx].b, ctx->events[idx].stream); }
 };
 static void drain_events(PtxContext* ctx) {
     if (ctx->events.empty()) return;
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     for (auto& e : ctx->events) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
@@ -1696,6 +1703,8 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
     const int shade_grid = (int)std::min<uint64_t>((uint64_t)256 * PT_SHADE_GRID_PER_CU, (n + SHADE_BLOCK - 1) / SHADE_BLOCK);
     const int final_grid = (int)std::min<uint64_t>(256 * 8, (n + SHADE_BLOCK - 1) / SHADE_BLOCK);
     bool drained = false;
+    const bool side = ctx->overlap_shadow && !ctx->counting && ctx->side_stream != nullptr;
+    bool side_pending = false;      // work on the side stream the main stream has not been ordered behind yet
     for (uint32_t it = 0; it < iter_cap; ++it) {
         uint32_t* qa = ctx->q[it & 1];
         uint32_t* qb = ctx->q[(it + 1) & 1];
@@ -1714,6 +1723,9 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
                 else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
             }
         }
+        // iteration it - 1's any-hit launch (side stream) zeroes the pending terms this k_shade adds, and reads the shadow
+        // and final queues this k_shade overwrites
+        if (side && it > 0) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0)); side_pending = false; }
         {
             ScopedEvent ev(ctx, CLS_SHADE);
             if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, dim3(final_grid), dim3(SHADE_BLOCK)   /* counted: few blocks, each ends with 7 counter atomics per wave */, 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, qwb, c, c + 1, max_bounces, ctx->d_counters);
@@ -1727,19 +1739,29 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
             if (ctx->counting) hipLaunchKernelGGL(k_sss_step<true>, dim3(std::min(wg, 256 * 8)), dim3(WALK_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qwa, qwb, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
             else hipLaunchKernelGGL(k_sss_step<false>, dim3(wg), dim3(WALK_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qwa, qwb, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
         }
+        // The any-hit launch and k_finalize of this iteration depend on this iteration's k_shade / k_sss_step only, and the
+        // next iteration's closest-hit launch does not depend on them: they go to the side stream and share the GPU with
+        // that launch, so neither kernel's tail (waves waiting for their last long ray) leaves the machine idle.
+        hipStream_t ss = side ? ctx->side_stream : ctx->stream;
+        uint2* sovf = side ? ctx->ovf_side : ctx->ovf;
+        if (side) {
+            HIPCHK(hipEventRecord(ctx->ev_main, ctx->stream));
+            HIPCHK(hipStreamWaitEvent(ss, ctx->ev_main, 0));
+        }
         {
-            ScopedEvent ev(ctx, CLS_SHADOW);
+            ScopedEvent ev(ctx, CLS_SHADOW, ss);
             const int sg = (int)std::min<uint64_t>(TRACE_GRID, (2ull * n + TRACE_BLOCK - 1) / TRACE_BLOCK);
             if (it == 0 && coherent && ctx->packet_shadow && !ctx->counting)
-                hipLaunchKernelGGL(k_shadow_packet, dim3(std::min(sg, PACKET_GRID)), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q_shadow, c, ctx->ovf, ctx->d_err,
+                hipLaunchKernelGGL(k_shadow_packet, dim3(std::min(sg, PACKET_GRID)), dim3(TRACE_BLOCK), 0, ss, ctx->S, ctx->P, ctx->q_shadow, c, sovf, ctx->d_err,
                                    ctx->S.nodes, ctx->S.tris, ctx->S.inst_tlas, ctx->S.inst, ctx->S.tlas_prims);
-            else if (ctx->counting) hipLaunchKernelGGL(k_shadow<true>, dim3(sg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q_shadow, c, ctx->ovf, ctx->d_counters, ctx->d_err);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(sg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q_shadow, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+            else if (ctx->counting) hipLaunchKernelGGL(k_shadow<true>, dim3(sg), dim3(TRACE_BLOCK), 0, ss, ctx->S, ctx->P, ctx->q_shadow, c, sovf, ctx->d_counters, ctx->d_err);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(sg), dim3(TRACE_BLOCK), 0, ss, ctx->S, ctx->P, ctx->q_shadow, c, sovf, ctx->d_counters, ctx->d_err);
         }
         {
-            ScopedEvent ev(ctx, CLS_ACCUM);
-            hipLaunchKernelGGL(k_finalize, dim3(final_grid), dim3(SHADE_BLOCK), 0, ctx->stream, ctx->P, ctx->q_final, c, tg, ctx->d_counters, ctx->counting ? 1u : 0u);
+            ScopedEvent ev(ctx, CLS_ACCUM, ss);
+            hipLaunchKernelGGL(k_finalize, dim3(final_grid), dim3(SHADE_BLOCK), 0, ss, ctx->P, ctx->q_final, c, tg, ctx->d_counters, ctx->counting ? 1u : 0u);
         }
+        if (side) { HIPCHK(hipEventRecord(ctx->ev_side, ss)); side_pending = true; }
         if (sss && it + 1 >= max_bounces && ((it + 1 - max_bounces) % SSS_POLL_EVERY == 0u || it + 1 == iter_cap)) {
             // subsurface walks make the iteration count data dependent: poll the live count every few iterations (the
             // launches of an iteration whose queues are empty leave in microseconds; a host round trip per iteration
@@ -1749,6 +1771,8 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
             if (ctx->h_pinned[16] == 0 && ctx->h_pinned[19] == 0) { drained = true; break; }
         }
     }
+    // whatever follows on the main stream (accumulation, readbacks, the next batch's k_raygen) comes after the side stream's work
+    if (side_pending) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
     HIPCHK(hipGetLastError());
     // Without SSS every path ends by iteration max_bounces (k_shade retires it at bounce >= max_bounces).  With SSS a
     // path that is still walking after MAX_ITERS - 1 iterations would never reach k_finalize: refuse instead of
@@ -1815,6 +1839,13 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
         }
     }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (const char* e = std::getenv("PTX_OVERLAP_SHADOW")) c->overlap_shadow = std::strtoul(e, nullptr, 10) != 0;
+    if (c->overlap_shadow) {
+        HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+        HIPCHK(hipMalloc((void**)&c->ovf_side, sizeof(uint2) * (size_t)std::max(TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
+    }
     HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * CTR_BLOCKS));
     HIPCHK(hipMalloc((void**)&c->ovf, sizeof(uint2) * (size_t)std::max(TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
     HIPCHK(hipMalloc((void**)&c->d_err, 4));
@@ -1838,6 +1869,10 @@ int32_t ptx_destroy(PtxContext* ctx) {
                     (void*)ctx->fb_sum, (void*)ctx->fb_sum_sq, (void*)ctx->fb_counts})
         if (p) (void)hipFree(p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
+    if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
+    if (ctx->ovf_side) (void)hipFree(ctx->ovf_side);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PTX_OK;

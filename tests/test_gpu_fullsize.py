@@ -323,3 +323,26 @@ def test_forwarded_bound_changes_no_hit_and_hits_sit_inside_their_boxes(pkg, loo
         assert 0.0 <= dbg["max_leaf_undershoot"] < 2.0 ** -9, (name, dbg)
         img = osc.render_pass(cam, 160, 90, 4, FULL[name][1])
         assert np.array_equal(bits(loop.render_pass(sc, cam, pkg.PathTracer(FULL[name][1]), 160, 90, 4)), bits(img)), name
+
+
+def test_side_stream_overlap_changes_nothing(pkg, oracle_det, full_scenes, monkeypatch):
+    """By default an iteration's any-hit launch and k_finalize run on a second stream beside the next iteration's
+    closest-hit launch (run_paths).  The frame must be the one-stream frame bit for bit — plain passes, several batches
+    in a row, adaptive passes and the subsurface walk queue — and equal the oracle's."""
+    sc = full_scenes("bistro_like")           # flags 3: sky + sun + SSS materials
+    w, h, spp, bounces = 192, 108, 6, 16
+    cam = sc.default_camera(w / h)
+    frames = []
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("PTX_OVERLAP_SHADOW", overlap)
+        monkeypatch.setenv("PTX_PATHS_IN_FLIGHT", str(w * h * 4))       # 6 passes = a batch of 4 + a batch of 2
+        lp = pkg.HipRenderLoop(0)
+        fb = pkg.DeviceFramebuffer(lp, w, h, adaptive=True)
+        fb.render_passes(sc, cam, pkg.PathTracer(bounces), 0, spp)
+        lp.render_adaptive_passes(sc, cam, pkg.PathTracer(bounces), fb, pkg.AdaptiveSamplingConfig(4, 0.0005), 3)
+        frames.append(fb.read())
+        one = lp.render_pass(sc, cam, pkg.PathTracer(bounces), w, h, 2)
+        frames[-1] = frames[-1] + (one,)
+    for a, b in zip(frames[0], frames[1]):
+        assert np.array_equal(bits(a), bits(b))
+    assert np.array_equal(bits(frames[0][3]), bits(oracle_det.scene(sc).render_pass(cam, w, h, 2, bounces)))

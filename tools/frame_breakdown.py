@@ -23,6 +23,9 @@ def main():
         scene = pkg.Scene.procedural(scene_name, 1, detail, flags)
         cam = scene.default_camera(w / h)
         loop = pkg.HipRenderLoop(0)
+        if os.environ.get("PT_PARTITION"):        # "rank,world": this rank's tiles only (what one GPU of N renders)
+            rank, world = (int(x) for x in os.environ["PT_PARTITION"].split(","))
+            loop.set_partition(rank, world)
         r = pkg.PathTracer(bounces)
         fb = pkg.DeviceFramebuffer(loop, w, h, adaptive=True)
         cfg = pkg.AdaptiveSamplingConfig(adaptive[0], adaptive[1]) if adaptive else None
@@ -38,6 +41,7 @@ def main():
             return out
 
         uniform(); adapt()                # warm-up
+        t0 = time.perf_counter(); uniform(); print(json.dumps({"config": name, "unprofiled_uniform_wall_s": round(time.perf_counter() - t0, 4)}), flush=True)
         for label, fn in (("uniform", uniform), ("adaptive", adapt)):
             if label == "uniform" or (adaptive and part != "uniform"):
                 if label == "adaptive" and part == "adaptive":

@@ -7,6 +7,9 @@ TAG=${1:-r01}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# one stream: every kernel's duration is then its own (by default the any-hit launch shares the GPU with the next
+# closest-hit launch and its dispatch time includes waiting for wave slots; k_extend's own duration is the same either way)
+export PTX_OVERLAP_SHADOW=0
 ARGS="--steps 1 --warmup 0 --no-cpu-baseline --spp 64 $*"
 run() { # name, then rocprofv3 options
   local name=$1; shift

@@ -6,6 +6,7 @@ TAG=$1; CFG=$2; PART=${3:-uniform}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export PTX_OVERLAP_SHADOW=0      # one stream: every kernel's duration is its own (see tools/profile.sh)
 run() { # name, then rocprofv3 options
   local name=$1; shift
   timeout -s KILL 300 rocprofv3 "$@" -d "$OUT/$name" --output-format csv -- python3 tools/frame_breakdown.py "$CFG" "$PART" > "$OUT/$name.log" 2>&1
