@@ -73,6 +73,11 @@ constexpr uint32_t PEND_SUN = 1u << 29, PEND_SKY = 1u << 30, PEND_POST = 1u << 3
 #define PT_PACKET_GRID_WAVES PT_WAVES_PER_SIMD
 #endif
 constexpr int PACKET_GRID = 256 * 4 * PT_PACKET_GRID_WAVES;   // the packet kernel needs fewer registers: more resident waves
+#ifndef PT_SHADOW_WAVES
+#define PT_SHADOW_WAVES PT_WAVES_PER_SIMD
+#endif
+constexpr int SHADOW_GRID = 256 * 4 * PT_SHADOW_WAVES;    // the any-hit kernel carries less state per lane
+constexpr int MAX_TRACE_GRID = 256 * 4 * (PT_SHADOW_WAVES > PT_WAVES_PER_SIMD ? PT_SHADOW_WAVES : PT_WAVES_PER_SIMD);
 constexpr int TRACE_GRID = 256 * 4 * PT_WAVES_PER_SIMD;   // persistent waves, PT_WAVES_PER_SIMD per SIMD: the VGPR and LDS budget
 #ifndef PT_SHADE_GRID_PER_CU
 #define PT_SHADE_GRID_PER_CU (1 << 20)
@@ -96,6 +101,9 @@ constexpr int SHADE_BLOCK = PT_SHADE_BLOCK;
 #endif
 #ifndef PT_TRACE_ATTR
 #define PT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_SIMD)))
+#endif
+#ifndef PT_SHADOW_ATTR
+#define PT_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADOW_WAVES)))
 #endif
 
 struct Target {
@@ -136,7 +144,7 @@ PT_DEV void wave_add(unsigned long long* dst, uint32_t v) {
 
 PT_DEV StackRef make_stack(uint2* ovf) {
     StackRef st;
-    st.ovf = ovf + (size_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    st.ovf = ovf;
     st.ovf_stride = (uint32_t)(gridDim.x * TRACE_BLOCK);
     return st;
 }
@@ -196,11 +204,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(Scene
                                                              uint8_t* out_any, uint32_t* work, uint2* ovf, DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
     LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f};
-    uint32_t nrays = 0, e = 0;
+    uint32_t nrays = 0;
     BatchSrc src{rays};
     BatchSink<ANY> sink{out_hits, out_any};
-    trace_queue<ANY, CNT>(S, st, work, n, src, sink, lc, nrays, e);
-    if (e) atomicOr(err, e);
+    trace_queue<ANY, CNT>(S, st, work, n, src, sink, lc, nrays, err);
     if (CNT) flush_lane_cnt(dc, lc, nrays, ANY);
 }
 
@@ -274,12 +281,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
     LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f};
-    uint32_t nrays = 0, e = 0;
+    uint32_t nrays = 0;
     const uint32_t n_active = ctr->n_active, n_walk = ctr->n_walk;
     ExtendSrc src{P, q, n_active, q_walk};
     ExtendSink sink{P};
-    trace_queue<false, CNT>(S, st, ctr->w_extend, n_active + n_walk, src, sink, lc, nrays, e);
-    if (e) atomicOr(err, e);
+    trace_queue<false, CNT>(S, st, ctr->w_extend, n_active + n_walk, src, sink, lc, nrays, err);
     if (CNT) flush_lane_cnt(dc, lc, nrays, false);
 }
 
@@ -303,11 +309,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend_redo(Scene
                                                              DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
     LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f};
-    uint32_t nrays = 0, e = 0;
+    uint32_t nrays = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
-    trace_queue<false, false>(S, st, ctr->w_extend, ctr->n_active, src, sink, lc, nrays, e);
-    if (e) atomicOr(err, e);
+    trace_queue<false, false>(S, st, ctr->w_extend, ctr->n_active, src, sink, lc, nrays, err);
     if (blockIdx.x == 0 && threadIdx.x == 0 && ctr->n_active)     // measurement: rays that took the redo road
         atomicAdd(reinterpret_cast<unsigned long long*>(&dc->dbg[2]), (unsigned long long)ctr->n_active);
 }
@@ -347,15 +352,14 @@ struct ShadowSink {
     }
 };
 template <bool CNT>
-__global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_shadow(SceneDev S, PathArrays P, const uint32_t* qs, IterCtr* ctr, uint2* ovf,
+__global__ __launch_bounds__(TRACE_BLOCK) PT_SHADOW_ATTR void k_shadow(SceneDev S, PathArrays P, const uint32_t* qs, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
     LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f};
-    uint32_t nrays = 0, e = 0;
+    uint32_t nrays = 0;
     ShadowSrc src{S, P, qs};
     ShadowSink sink{P};
-    trace_queue<true, CNT>(S, st, ctr->w_shadow, ctr->n_shadow, src, sink, lc, nrays, e);
-    if (e) atomicOr(err, e);
+    trace_queue<true, CNT>(S, st, ctr->w_shadow, ctr->n_shadow, src, sink, lc, nrays, err);
     if (CNT) flush_lane_cnt(dc, lc, nrays, true);
 }
 
@@ -1750,7 +1754,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
         }
         {
             ScopedEvent ev(ctx, CLS_SHADOW, ss);
-            const int sg = (int)std::min<uint64_t>(TRACE_GRID, (2ull * n + TRACE_BLOCK - 1) / TRACE_BLOCK);
+            const int sg = (int)std::min<uint64_t>(SHADOW_GRID, (2ull * n + TRACE_BLOCK - 1) / TRACE_BLOCK);
             if (it == 0 && coherent && ctx->packet_shadow && !ctx->counting)
                 hipLaunchKernelGGL(k_shadow_packet, dim3(std::min(sg, PACKET_GRID)), dim3(TRACE_BLOCK), 0, ss, ctx->S, ctx->P, ctx->q_shadow, c, sovf, ctx->d_err,
                                    ctx->S.nodes, ctx->S.tris, ctx->S.inst_tlas, ctx->S.inst, ctx->S.tlas_prims);
@@ -1844,10 +1848,10 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
         HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
-        HIPCHK(hipMalloc((void**)&c->ovf_side, sizeof(uint2) * (size_t)std::max(TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
+        HIPCHK(hipMalloc((void**)&c->ovf_side, sizeof(uint2) * (size_t)std::max(MAX_TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
     }
     HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * CTR_BLOCKS));
-    HIPCHK(hipMalloc((void**)&c->ovf, sizeof(uint2) * (size_t)std::max(TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
+    HIPCHK(hipMalloc((void**)&c->ovf, sizeof(uint2) * (size_t)std::max(MAX_TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
     HIPCHK(hipMalloc((void**)&c->d_err, 4));
     HIPCHK(hipMemset(c->d_err, 0, 4));
     HIPCHK(hipMalloc((void**)&c->d_counters, sizeof(DevCounters)));

@@ -127,13 +127,20 @@ constexpr uint32_t QUEUE_SEGMENTS = 1u << QUEUE_SEGMENT_SHIFT;
 constexpr uint32_t SEGMENT_MIN_QUEUE = PT_SEGMENT_MIN_QUEUE;   // queues shorter than this use one cursor
 
 struct StackRef {
-    uint2* ovf;            // &ovf[0][global_lane], entry stride = ovf_stride
+    uint2* ovf;            // the strips of the whole grid (wave-uniform); a lane's entry k is ovf[k * ovf_stride + strip_lane()]
     uint32_t ovf_stride;
 };
+// A lane's column in the spill strips.  Recomputed at every use (the asm keeps the compiler from hoisting the 64-bit
+// lane address out of the traversal loop, where it would occupy two registers for the sake of a rare access).
+PT_DEV uint32_t strip_lane() {
+    uint32_t t = blockIdx.x * 64u + threadIdx.x;      // TRACE_BLOCK == 64
+    asm volatile("" : "+v"(t));
+    return t;
+}
 PT_DEV void st_write(const StackRef& s, int i, uint32_t word, uint32_t dist_bits) {
     const uint2 v = make_uint2(word, dist_bits);
     if (i < LDS_STACK) s_stack[i * TRACE_BLOCK + (int)threadIdx.x] = v;
-    else s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride] = v;
+    else s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride + strip_lane()] = v;
 }
 PT_DEV uint2 st_read(const StackRef& s, int i) {
     // Two real branches, one load each.  Left alone, the compiler turns "LDS load or HBM load" into one FLAT load of a
@@ -144,7 +151,7 @@ PT_DEV uint2 st_read(const StackRef& s, int i) {
         v = s_stack[i * TRACE_BLOCK + (int)threadIdx.x];
         asm volatile("" : "+v"(v.x), "+v"(v.y));
     } else {
-        v = s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride];
+        v = s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride + strip_lane()];
     }
     return v;
 }
@@ -290,13 +297,13 @@ struct Traverser {
     // builder never has one), so the fourth child and the second unit are compiled out.
     // r0..r5 = children 0..2 of the unit visited FIRST: the second unit when the record has one (children 4..6), else the first.
     template <bool EXACT, bool WIDE>
-    PT_DEV void do_node(const SceneDev& S, const StackRef& st, LaneCnt& lc, uint32_t& err, const float4 r0, const float4 r1,
+    PT_DEV void do_node(const SceneDev& S, const StackRef& st, LaneCnt& lc, uint32_t* err, const float4 r0, const float4 r1,
                         const float4 r2, const float4 r3, const float4 r4, const float4 r5) {
         const uint32_t nchild = ((pw >> NODE_NCHILD_SHIFT) & NODE_NCHILD_MASK) + 1u;
         const float4* p = reinterpret_cast<const float4*>(&S.nodes[pw & NODE_INDEX_MASK]);
         // the device stack (all levels of one ray share it) holds STACK_CAP entries; the reference's fixed arrays hold
         // 64 per level and panic beyond (accel/bvh.rs:320,361,379,408)
-        if (sp + (int)nchild > STACK_CAP) { err = 1u; found = false; act = ACT_DONE; return; }
+        if (sp + (int)nchild > STACK_CAP) { atomicOr(err, 1u); found = false; act = ACT_DONE; return; }
         act = ACT_POP;
         if (WIDE && nchild > 4u) {
             // a record of two units: its children 7..4 now (they are pushed first), its children 3..0 in the lane's next
@@ -341,7 +348,7 @@ struct Traverser {
     }
 
     // ---- ACT_ENTER: Instance::hit / hit_any head + the Blas-level box ---------------------
-    PT_DEV void do_enter(const SceneDev& S, const StackRef& st, LaneCnt& lc, uint32_t& err) {
+    PT_DEV void do_enter(const SceneDev& S, const StackRef& st, LaneCnt& lc, uint32_t* err) {
         const float tmin = RAY_EPSILON;
         const uint32_t start = pw & PRIM_START_MASK;
         const uint32_t count = ((pw >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
@@ -349,7 +356,7 @@ struct Traverser {
         const float4 ia = p[0], ib = p[1], ic = p[2], b0 = p[3], b1 = p[4];
         const uint32_t inst_idx = S.tlas_prims[start];
         // TLAS leaf: this primitive now, the rest after the instance has been left
-        if (sp + 4 > STACK_CAP) { err = 1u; found = false; act = ACT_DONE; return; }     // remainder + 3-entry marker
+        if (sp + 4 > STACK_CAP) { atomicOr(err, 1u); found = false; act = ACT_DONE; return; }     // remainder + 3-entry marker
         if (count > 1u) st_write(st, sp++, LEAF_FLAG | ((count - 2u) << PRIM_COUNT_SHIFT) | (start + 1u), NEG_INF_BITS);
         if (CNT) { lc.prim_reads++; lc.inst_entries++; lc.node_visits++; lc.node_children++; }
         const V3 lo = xf_point(ia, ib, ic, o);
@@ -420,7 +427,7 @@ struct Traverser {
 // `work` is the queue's shared cursor, `n` its length.
 template <bool ANY, bool CNT, class Src, class Sink>
 PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink,
-                        LaneCnt& lc, uint32_t& nrays, uint32_t& err) {
+                        LaneCnt& lc, uint32_t& nrays, uint32_t* err) {      // err: the device error word (set on a stack overflow)
     // a short queue cannot feed every wave: the surplus ones leave without touching the cursors (6144 waves bumping
     // a few addresses made an empty launch cost 70 us)
     if ((unsigned long long)blockIdx.x * 16ull >= (unsigned long long)n + 128ull) return;
@@ -450,7 +457,9 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
             const uint32_t hi = lo + seg_size < n ? lo + seg_size : n;
             uint32_t basei = 0;
             if ((int)lane == leader) basei = atomicAdd(&work[seg], n_idle);
-            basei = lo + __shfl(basei, leader);
+            // v_readlane, not a shuffle: the compiler then knows that the claim, and the segment bookkeeping that depends
+            // on it, are wave-uniform and keeps them in scalar registers
+            basei = lo + (uint32_t)__builtin_amdgcn_readlane((int)basei, leader);
             if (tv.act == ACT_IDLE) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t i = basei + rank;
@@ -537,7 +546,7 @@ PT_DEV void pk_write(const StackRef& s, int i, uint32_t word, uint32_t dist_bits
         s_pdist[i * TRACE_BLOCK + (int)threadIdx.x] = dist_bits;
         s_pword[i] = word;
     } else {
-        s.ovf[(size_t)(i - PACKET_LDS) * s.ovf_stride] = make_uint2(word, dist_bits);
+        s.ovf[(size_t)(i - PACKET_LDS) * s.ovf_stride + strip_lane()] = make_uint2(word, dist_bits);
     }
 }
 PT_DEV uint2 pk_read(const StackRef& s, int i) {
@@ -547,7 +556,7 @@ PT_DEV uint2 pk_read(const StackRef& s, int i) {
         v.y = s_pdist[i * TRACE_BLOCK + (int)threadIdx.x];
         asm volatile("" : "+v"(v.x), "+v"(v.y));
     } else {
-        v = s.ovf[(size_t)(i - PACKET_LDS) * s.ovf_stride];
+        v = s.ovf[(size_t)(i - PACKET_LDS) * s.ovf_stride + strip_lane()];
     }
     return v;
 }
