@@ -212,7 +212,7 @@ def main():
     # `traffic` / `measured_hbm_frac` (PMC counters) are, and `limiters` names what actually binds the kernel.
     roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "measured_hbm_frac": None,
-                "frac_meaning": "algorithmic (reference byte stream, SURVEY 8d) bytes / launch time / 8 TB/s; NOT HBM utilisation, see measured_hbm_frac and limiters",
+                "frac_meaning": "algorithmic (reference byte stream, SURVEY 8d: what the reference's walk touches, from the counted kernels) bytes / launch time / 8 TB/s; NOT HBM utilisation and can exceed 1: caches serve most of the stream and the timed kernels skip part of it (forwarded bound). See measured_hbm_frac and limiters",
                 "algorithmic_bytes_per_launch": round(ext_bytes_launch), "avg_launch_ms": round(ext_ms, 4),
                 "launches": int(ext_launches)}
     if pk_launches:
