@@ -70,7 +70,7 @@ def main():
         })
         print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
         del loop, scene
-    print("| config | resolution / spp | CPU port (cores) s/frame (extrapolated) | CPU Mprimary/s | 1×MI355X s/frame | Mprimary/s | Mrays/s (all) | algorithmic B/ray | % of 8 TB/s HBM |")
+    print("| config | resolution / spp | CPU port (cores) s/frame (extrapolated) | CPU Mprimary/s | 1×MI355X s/frame | Mprimary/s | Mrays/s (all) | algorithmic B/ray | reference byte stream ÷ 8 TB/s (NOT HBM utilisation) |")
     print("|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         print(f"| {r['config']} ({r['triangles']:,} tris, {r['instances']} inst) | {r['res_spp']} | {r['cpu_s_per_frame_extrapolated']} ({r['cpu_cores']}) | "
