@@ -422,6 +422,10 @@ typedef struct PtxDebugStats {
     float max_leaf_undershoot;   /* counted kernels: largest (t_enter(leaf box) - t) / t over all triangle hits computed */
     uint32_t bound_forwarding;   /* 1 = closest-hit rays take the world closest_t into instances, 0 = off for this scene */
     uint32_t _pad;
+    /* The wave vote of the counted per-ray kernels since ptx_reset_counters: [0] loop iterations summed over waves,
+     * [1..4] iterations in which the NODE / TRI / ENTER / EXIT action ran, [5..8] lanes that took part in it. */
+    uint64_t vote_closest[9];
+    uint64_t vote_any[9];
 } PtxDebugStats;
 int32_t ptx_get_debug_stats(PtxContext* ctx, PtxDebugStats* out);
 

@@ -158,7 +158,9 @@ PT_DEV uint2 st_read(const StackRef& s, int i) {
 
 // stack_hw: deepest stack this lane reached; undershoot: largest (t_enter(leaf box) - t) / t over the triangle hits this
 // lane computed (how far a hit can lie in front of the boxes above it: forwarded_bound tolerates 2^-5) — counted kernels
-struct LaneCnt { uint32_t node_visits, node_children, prim_reads, tri_tests, inst_entries, inst_hits, stack_hw; float undershoot; };
+// vote[0] = loop iterations of this wave, vote[1..4] = iterations in which the NODE / TRI / ENTER / EXIT action ran,
+// vote[5..8] = lanes that took part in it (wave-uniform values; lane 0's copy is flushed)
+struct LaneCnt { uint32_t node_visits, node_children, prim_reads, tri_tests, inst_entries, inst_hits, stack_hw; float undershoot; uint32_t vote[9]; };
 
 PT_DEV V3 xf_point(const float4 a, const float4 b, const float4 c, V3 p) {
     // Mat4::transform_point3: ((x_axis*x + y_axis*y) + z_axis*z) + w_axis, packed columns
@@ -490,6 +492,13 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
         if (mx == 0u) {
             if (exhausted) break;
             continue;
+        }
+        if (CNT) {
+            lc.vote[0]++;
+            if (cn == mx || cn >= (ANY ? TH_ANY : TH_NODE)) { lc.vote[1]++; lc.vote[5] += cn; }
+            if (ctn == mx || ctn >= (ANY ? TH_ANY : TH_TRI)) { lc.vote[2]++; lc.vote[6] += ctn; }
+            if (ce == mx || ce >= (ANY ? TH_ANY : TH_ENTER)) { lc.vote[3]++; lc.vote[7] += ce; }
+            if (cx == mx || cx >= (ANY ? TH_ANY : TH_EXIT)) { lc.vote[4]++; lc.vote[8] += cx; }
         }
         if (cx == mx || cx >= (ANY ? TH_ANY : TH_EXIT)) {
             if (tv.act == ACT_EXIT) tv.do_exit(S, st, lc, src, sink, my);

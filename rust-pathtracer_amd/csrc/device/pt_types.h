@@ -152,6 +152,8 @@ struct DevCounters {
     // PtxDebugStats (not part of PtxCounters): [0] deepest per-ray stack (counted kernels), [1] deepest packet stack,
     // [2..3] rays handed from overflowed packets to k_extend_redo (u64), [4] largest leaf undershoot (f32 bits, counted kernels)
     unsigned int dbg[6];
+    // the wave vote of the counted per-ray kernels (LaneCnt::vote), closest-hit [0..8] then any-hit [9..17]
+    unsigned long long vote[18];
 };
 enum CounterId {
     C_RAYS_CLOSEST, C_RAYS_ANY, C_NODE_VISITS, C_NODE_CHILDREN, C_PRIM_INDEX_READS, C_TRI_TESTS,

@@ -288,7 +288,13 @@ class HipRenderLoop:
         """Stack high-water marks and packet-redo count since the last `reset_counters` (which traversal paths ran)."""
         d = abi.PtxDebugStats()
         self._check(self.L.ptx_get_debug_stats(self._h, C.byref(d)), "ptx_get_debug_stats")
-        return {n: (float(getattr(d, n)) if n == "max_leaf_undershoot" else int(getattr(d, n))) for n, _ in abi.PtxDebugStats._fields_ if n != "_pad"}
+        out = {}
+        for n, _ in abi.PtxDebugStats._fields_:
+            v = getattr(d, n)
+            if n == "_pad":
+                continue
+            out[n] = float(v) if n == "max_leaf_undershoot" else ([int(x) for x in v] if n.startswith("vote_") else int(v))
+        return out
 
     def set_profiling(self, on):
         self._check(self.L.ptx_set_profiling(self._h, 1 if on else 0), "ptx_set_profiling")

@@ -89,6 +89,10 @@ def test_full_detail_hit_records_bit_exact(pkg, loop, oracle_det, full_scenes, m
               f"(LDS holds {dbg['lds_stack_entries']}), packet stack high-water {pdbg['packet_stack_high_water']} "
               f"(LDS holds {pdbg['packet_lds_entries']}, capacity {pdbg['packet_capacity']}); "
               f"node visits/ray {gc['node_visits'] / max(1, gc['rays_closest'] + gc['rays_any']):.1f}")
+        # the wave vote of the counted kernels: every action ran, and a lane-action count is the oracle's event count
+        vc, va = dbg["vote_closest"], dbg["vote_any"]
+        assert vc[0] > 0 and va[0] > 0 and all(vc[1 + k] <= vc[0] and 0 < vc[5 + k] <= 64 * vc[1 + k] for k in range(4)), (vc, va)
+        assert vc[6] + va[6] == gc["triangle_tests"], (vc, va, gc["triangle_tests"])       # one TRI lane-action = one triangle test
         if name != "sponza_like" or label == "secondary":
             # the deep trees do leave the LDS part of the stack: the HBM strips are exercised
             assert dbg["trace_stack_high_water"] > dbg["lds_stack_entries"], (name, label, dbg)

@@ -35,10 +35,15 @@ def main():
         loop.reset_counters()
         g = loop.trace_closest(scene, r)
         c = loop.counters()
+        dbg = loop.debug_stats()
         loop.set_counting(False)
         n = max(1, c["rays_closest"])
         print(f"{label:48s} node visits {c['node_visits'] / n:6.1f}  tri tests {c['triangle_tests'] / n:6.1f}  instance entries {c['instance_entries'] / n:5.1f}"
               f"  instance hits {c['instance_hits'] / n:5.2f}")
+        v = dbg["vote_closest"]
+        names = ("NODE", "TRI", "ENTER", "EXIT")
+        print("    vote: " + ", ".join(f"{names[k]} runs in {v[1 + k] / max(1, v[0]):.2f} of iterations with {v[5 + k] / max(1, v[1 + k]):.1f} lanes" for k in range(4)) +
+              f"; {v[0] / n:.1f} wave iterations per ray x 64")
         return g
     count(ref, rays, "(a) reference walk")
     os.environ["PTX_COUNT_FORWARD"] = "1"
