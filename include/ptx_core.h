@@ -426,6 +426,9 @@ typedef struct PtxDebugStats {
      * [1..4] iterations in which the NODE / TRI / ENTER / EXIT action ran, [5..8] lanes that took part in it. */
     uint64_t vote_closest[9];
     uint64_t vote_any[9];
+    /* counted per-ray kernels: stack entries popped, popped from the per-lane HBM strips (index >= lds_stack_entries),
+     * children pushed, pushed to the strips */
+    uint64_t stack_ops[4];
 } PtxDebugStats;
 int32_t ptx_get_debug_stats(PtxContext* ctx, PtxDebugStats* out);
 

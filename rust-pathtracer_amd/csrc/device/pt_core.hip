@@ -167,6 +167,8 @@ PT_DEV void flush_lane_cnt(DevCounters* dc, const LaneCnt& lc, uint32_t rays, bo
       if ((threadIdx.x & 63u) == 0u && us > 0.0f) atomicMax(&dc->dbg[4], __float_as_uint(us)); }
     if ((threadIdx.x & 63u) == 0u)
         for (int k = 0; k < 9; ++k) atomicAdd(&dc->vote[(any ? 9 : 0) + k], (unsigned long long)lc.vote[k]);
+    wave_add(&dc->stk[0], lc.stk_reads); wave_add(&dc->stk[1], lc.stk_reads_hbm);
+    wave_add(&dc->stk[2], lc.stk_writes); wave_add(&dc->stk[3], lc.stk_writes_hbm);
     if (any) {
         wave_add(&dc->v[C_ANY_NODE_VISITS], lc.node_visits);
         wave_add(&dc->v[C_ANY_NODE_CHILDREN], lc.node_children);
@@ -205,7 +207,7 @@ template <bool ANY, bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
                                                              uint8_t* out_any, uint32_t* work, uint2* ovf, DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0};
     uint32_t nrays = 0;
     BatchSrc src{rays};
     BatchSink<ANY> sink{out_hits, out_any};
@@ -282,7 +284,7 @@ template <bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S, PathArrays P, const uint32_t* q, const uint32_t* q_walk, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0};
     uint32_t nrays = 0;
     const uint32_t n_active = ctr->n_active, n_walk = ctr->n_walk;
     ExtendSrc src{P, q, n_active, q_walk};
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_extend_packet(Sc
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend_redo(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
                                                              DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0};
     uint32_t nrays = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
@@ -357,7 +359,7 @@ template <bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_SHADOW_ATTR void k_shadow(SceneDev S, PathArrays P, const uint32_t* qs, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0};
     uint32_t nrays = 0;
     ShadowSrc src{S, P, qs};
     ShadowSink sink{P};
@@ -2670,6 +2672,7 @@ int32_t ptx_get_debug_stats(PtxContext* ctx, PtxDebugStats* out) {
     HIPCHK(hipMemcpy(dbg, ctx->d_counters->dbg, sizeof(dbg), hipMemcpyDeviceToHost));
     std::memcpy(&out->max_leaf_undershoot, &dbg[4], 4);
     HIPCHK(hipMemcpy(out->vote_closest, ctx->d_counters->vote, sizeof(uint64_t) * 18, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out->stack_ops, ctx->d_counters->stk, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
     out->bound_forwarding = ctx->has_scene ? ctx->S.fwd_on : 0u;
     out->_pad = 0;
     out->trace_stack_high_water = dbg[0];

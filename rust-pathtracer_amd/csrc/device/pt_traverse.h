@@ -160,7 +160,8 @@ PT_DEV uint2 st_read(const StackRef& s, int i) {
 // lane computed (how far a hit can lie in front of the boxes above it: forwarded_bound tolerates 2^-5) — counted kernels
 // vote[0] = loop iterations of this wave, vote[1..4] = iterations in which the NODE / TRI / ENTER / EXIT action ran,
 // vote[5..8] = lanes that took part in it (wave-uniform values; lane 0's copy is flushed)
-struct LaneCnt { uint32_t node_visits, node_children, prim_reads, tri_tests, inst_entries, inst_hits, stack_hw; float undershoot; uint32_t vote[9]; };
+struct LaneCnt { uint32_t node_visits, node_children, prim_reads, tri_tests, inst_entries, inst_hits, stack_hw; float undershoot; uint32_t vote[9];
+                 uint32_t stk_reads, stk_reads_hbm, stk_writes, stk_writes_hbm; };   // per lane: stack entries read / written, and those in the HBM strip
 
 PT_DEV V3 xf_point(const float4 a, const float4 b, const float4 c, V3 p) {
     // Mat4::transform_point3: ((x_axis*x + y_axis*y) + z_axis*z) + w_axis, packed columns
@@ -234,6 +235,7 @@ struct Traverser {
     uint32_t tri_cnt;          // TRI: triangles left in the leaf
     bool in_mesh, found, exact;
     float leaf_dist;           // counted kernels: entry distance of the leaf whose triangles are being tested
+    LaneCnt* lcp;              // counted kernels: the lane's counters (visit_child has no other way to them)
 
     // which tree the current level is walked in: the faithful one for NaN-slab rays and for the counted kernels
     PT_DEV bool faithful() const { return CNT || exact; }
@@ -253,10 +255,11 @@ struct Traverser {
     }
 
     // ---- pop entries until one needs work; sets the next action (accel/bvh.rs:322-329) ---------------
-    PT_DEV void pop(const StackRef& st) {
+    PT_DEV void pop(const StackRef& st, LaneCnt& lc) {
         for (;;) {
             if (sp == 0) { act = ACT_DONE; return; }
             --sp;
+            if (CNT) { lc.stk_reads++; if (sp >= LDS_STACK) lc.stk_reads_hbm++; }
             const uint2 e = st_read(st, sp);
             if (!ANY && __uint_as_float(e.y) >= ct) continue;
             pw = e.x;
@@ -281,6 +284,7 @@ struct Traverser {
         float te;
         const bool h = box_test<EXACT>(lo, hi, o, inv, RAY_EPSILON, ct, &te) && valid;
         if (h) {
+            if (CNT) { lcp->stk_writes++; if (sp >= LDS_STACK) lcp->stk_writes_hbm++; }
             const uint32_t w = __float_as_uint(hi.z);
             st_write(st, sp, w, __float_as_uint(te));
             ++sp;
@@ -438,7 +442,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
     tv.exact = false; tv.in_mesh = false; tv.found = false;
     tv.sp = 0; tv.pw = 0; tv.tri_cnt = 0; tv.tri_base = 0; tv.m_tri = PTX_MISS; tv.m_u = 0.0f; tv.m_v = 0.0f;
     tv.ct = 0.0f; tv.o = v3(0.0f, 0.0f, 0.0f); tv.d = tv.o; tv.inv = tv.o;
-    tv.leaf_dist = 0.0f;
+    tv.leaf_dist = 0.0f; tv.lcp = nullptr;
     uint32_t my = 0;
     // Idle lanes claim queue entries with one wave-aggregated atomic as soon as REFILL_MIN_IDLE of them have
     // gathered.  (Claiming a chunk ahead of need was measured and rejected: a launch lasts only ~16 ray lifetimes,
@@ -479,7 +483,8 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
                 if (--seg_left == 0u) exhausted = true;
             }
         }
-        if (tv.act == ACT_POP) tv.pop(st);
+        if (CNT) tv.lcp = &lc;
+        if (tv.act == ACT_POP) tv.pop(st, lc);
         if (tv.act == ACT_DONE) { sink.done(my, tv.found); tv.act = ACT_IDLE; }
 
         // vote: the action most lanes are waiting for runs, and so does any other with RUN_THRESHOLD lanes waiting

@@ -154,6 +154,7 @@ struct DevCounters {
     unsigned int dbg[6];
     // the wave vote of the counted per-ray kernels (LaneCnt::vote), closest-hit [0..8] then any-hit [9..17]
     unsigned long long vote[18];
+    unsigned long long stk[4];     // counted per-ray kernels: node-visit stack entries read, read from the HBM strips, written, written to the strips
 };
 enum CounterId {
     C_RAYS_CLOSEST, C_RAYS_ANY, C_NODE_VISITS, C_NODE_CHILDREN, C_PRIM_INDEX_READS, C_TRI_TESTS,

@@ -23,6 +23,8 @@ def main():
     c = loop.counters()
     d = loop.debug_stats()
     loop.set_counting(False)
+    so = d["stack_ops"]
+    print(f"stack: {so[0]} pops, {so[1] / max(1, so[0]):.3f} of them from the HBM strips; {so[2]} child pushes, {so[3] / max(1, so[2]):.3f} to the strips")
     names = ("NODE", "TRI", "ENTER", "EXIT")
     for label, v, rays in (("closest", d["vote_closest"], c["rays_closest"]), ("any-hit", d["vote_any"], c["rays_any"])):
         print(f"{label}: {rays} rays, {v[0]} wave iterations = {v[0] * 64 / max(1, rays):.1f} lane-iterations per ray")
