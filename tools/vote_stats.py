@@ -11,18 +11,22 @@ import __graft_entry__ as ge  # noqa: E402
 
 def main():
     pkg = ge.load_package()
-    scene = pkg.Scene.procedural("bistro_like", 1, 1.0, 1)
+    name = sys.argv[1] if len(sys.argv) > 1 else "bistro_like"
+    bounces = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    scene = pkg.Scene.procedural(name, 1, 1.0, 0 if name == "instanced_stress" else 1)
     w, h, spp = 1920, 1080, 16
     cam = scene.default_camera(w / h)
     loop = pkg.HipRenderLoop(0)
     fb = pkg.DeviceFramebuffer(loop, w, h, adaptive=True)
     loop.set_counting(True)
     loop.reset_counters()
-    fb.render_passes(scene, cam, pkg.PathTracer(16), 0, spp)
+    fb.render_passes(scene, cam, pkg.PathTracer(bounces), 0, spp)
     loop.sync()
     c = loop.counters()
     d = loop.debug_stats()
     loop.set_counting(False)
+    n = max(1, c["rays_closest"])
+    print(f"{name}: per closest-hit ray {c['node_visits'] / (n + c['rays_any']):.1f} node visits (all rays), {c['instance_entries'] / (n + c['rays_any']):.1f} instance entries, {c['triangle_tests'] / (n + c['rays_any']):.1f} triangle tests")
     so = d["stack_ops"]
     print(f"stack: {so[0]} pops, {so[1] / max(1, so[0]):.3f} of them from the HBM strips; {so[2]} child pushes, {so[3] / max(1, so[2]):.3f} to the strips")
     names = ("NODE", "TRI", "ENTER", "EXIT")
