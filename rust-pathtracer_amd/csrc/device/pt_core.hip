@@ -203,7 +203,7 @@ struct BatchSink {
         else if (!found) hit(i, PTX_MISS, PTX_MISS, PT_INF, 0.0f, 0.0f);
     }
 };
-template <bool ANY, bool CNT>
+template <bool ANY, bool CNT, bool FAST = false>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
                                                              uint8_t* out_any, uint32_t* work, uint2* ovf, DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(Scene
     uint32_t nrays = 0;
     BatchSrc src{rays};
     BatchSink<ANY> sink{out_hits, out_any};
-    trace_queue<ANY, CNT>(S, st, work, n, src, sink, lc, nrays, err);
+    trace_queue<ANY, CNT, FAST>(S, st, work, n, src, sink, lc, nrays, err, reinterpret_cast<unsigned long long*>(&dc->dbg[6]));
     if (CNT) flush_lane_cnt(dc, lc, nrays, ANY);
 }
 
@@ -280,7 +280,8 @@ struct ExtendSink {
         if (!found) hit(i, PTX_MISS, PTX_MISS, PT_INF, 0.0f, 0.0f);
     }
 };
-template <bool CNT>
+// FAST: nearest child first + the order-independence check (pt_traverse.h); a ray that fails the check is traced again, in reference order, by its lane
+template <bool CNT, bool FAST = false>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S, PathArrays P, const uint32_t* q, const uint32_t* q_walk, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S
     const uint32_t n_active = ctr->n_active, n_walk = ctr->n_walk;
     ExtendSrc src{P, q, n_active, q_walk};
     ExtendSink sink{P};
-    trace_queue<false, CNT>(S, st, ctr->w_extend, n_active + n_walk, src, sink, lc, nrays, err);
+    trace_queue<false, CNT, FAST>(S, st, ctr->w_extend, n_active + n_walk, src, sink, lc, nrays, err, reinterpret_cast<unsigned long long*>(&dc->dbg[6]));
     if (CNT) flush_lane_cnt(dc, lc, nrays, false);
 }
 
@@ -1726,9 +1727,11 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
                 st = launch_primary_packets(ctx, qa, c, n);
                 if (st != PTX_OK) return st;
             } else {
+                const bool fast = ctx->S.fast_on != 0u && !ctx->counting;
                 ScopedEvent ev(ctx, CLS_EXTEND);
-                if (ctx->counting) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
-                else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                if (ctx->counting) hipLaunchKernelGGL((k_extend<true, false>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                else if (fast) hipLaunchKernelGGL((k_extend<false, true>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                else hipLaunchKernelGGL((k_extend<false, false>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
             }
         }
         // iteration it - 1's any-hit launch (side stream) zeroes the pending terms this k_shade adds, and reads the shadow
@@ -2119,6 +2122,28 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
         // measurement only: PTX_COUNT_FORWARD=1 lets the counted kernels forward too (their counts are then this library's, not the reference's)
         if (S.fwd_on) { const char* cf = std::getenv("PTX_COUNT_FORWARD"); if (cf && cf[0] == '1') S.fwd_on = 2u; }
         S.fwd_lin = (float)(lin * 1.0000002); S.fwd_t = (float)(tr * 1.0000002);
+        // FAST traversal: on with forwarding (same presumptions), for rays that start within the scene's extent
+        {
+            double omax = 0.0;      // max |p|_1 over the world boxes of the instances, doubled: rays that start on or near a surface
+            for (uint32_t i = 0; i < sc->n_instances; ++i) {
+                const float* M = sc->instances[i].transform;
+                const PtxMesh& m = sc->meshes[sc->instances[i].blas_index];
+                for (int corner = 0; corner < 8; ++corner) {
+                    const double x = (corner & 1) ? m.bounds_max[0] : m.bounds_min[0], y = (corner & 2) ? m.bounds_max[1] : m.bounds_min[1],
+                                 z = (corner & 4) ? m.bounds_max[2] : m.bounds_min[2];
+                    double l1 = 0.0;
+                    for (int r = 0; r < 3; ++r) l1 += std::fabs((double)M[r] * x + (double)M[4 + r] * y + (double)M[8 + r] * z + (double)M[12 + r]);
+                    if (l1 == l1 && l1 > omax) omax = l1;
+                }
+            }
+            omax = 2.0 * omax + 1.0;
+            const double slack = 1.5 * (lin * omax + tr) * 1.0000002;
+            const char* exact_order = std::getenv("PTX_EXACT_ORDER");
+            S.fast_on = (S.fwd_on == 1u && omax < 1e30 && slack < 1e30 && !(exact_order && exact_order[0] == '1')) ? 1u : 0u;
+            S.fast_omax = (float)omax; S.fast_slack = (float)slack;
+            S.fast_cull = FAST_CULL; S.fast_band = FAST_BAND;
+            if (std::getenv("PTX_VERBOSE")) fprintf(stderr, "[ptx] forwarding %u (lin %.3g, tr %.3g); nearest-first %u (|o|_1 <= %.4g, slack %.3g)\n", S.fwd_on, lin, tr, S.fast_on, omax, slack);
+        }
     }
     // shading triangles: built on the device from the pools just uploaded, one launch per mesh
     {
@@ -2183,7 +2208,7 @@ static int32_t render_to_images(PtxContext* ctx, uint32_t w, uint32_t h, uint32_
                 const int32_t ps = launch_primary_packets(ctx, ctx->q[0], ctx->ctrs, n);
                 if (ps != PTX_OK) return ps;
             } else
-                hipLaunchKernelGGL(k_extend<false>, dim3(tg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q[0], (const uint32_t*)nullptr, ctx->ctrs, ctx->ovf, ctx->d_counters, ctx->d_err);
+                hipLaunchKernelGGL((k_extend<false, false>), dim3(tg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, ctx->q[0], (const uint32_t*)nullptr, ctx->ctrs, ctx->ovf, ctx->d_counters, ctx->d_err);
             hipLaunchKernelGGL(k_unshaded, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, ctx->P, n, d_rgb);
         }
     } else {
@@ -2574,6 +2599,7 @@ int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t
             hipLaunchKernelGGL(k_trace_batch_packet<false>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_err, ctx->d_counters);
         } else {
             if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
+            else if (ctx->S.fast_on) hipLaunchKernelGGL((k_trace_batch<false, false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
         }
         delete ev;
@@ -2606,6 +2632,7 @@ int32_t ptx_trace_batch_noalloc(PtxContext* ctx, const PtxRay* d_rays, uint64_t 
         else hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, d_out_any, d_work, d_ovf, ctx->d_counters, d_err);
     } else {
         if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, d_out_hits, (uint8_t*)nullptr, d_work, d_ovf, ctx->d_counters, d_err);
+        else if (ctx->S.fast_on) hipLaunchKernelGGL((k_trace_batch<false, false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, d_out_hits, (uint8_t*)nullptr, d_work, d_ovf, ctx->d_counters, d_err);
         else hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, d_out_hits, (uint8_t*)nullptr, d_work, d_ovf, ctx->d_counters, d_err);
     }
     HIPCHK(hipGetLastError());
@@ -2668,8 +2695,11 @@ int32_t ptx_get_debug_stats(PtxContext* ctx, PtxDebugStats* out) {
     REQUIRE_CTX();
     if (!out) return fail(ctx, PTX_ERR_INVALID, "null output");
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    unsigned int dbg[6];
+    unsigned int dbg[8];
     HIPCHK(hipMemcpy(dbg, ctx->d_counters->dbg, sizeof(dbg), hipMemcpyDeviceToHost));
+    out->fast_redo_rays = (uint64_t)dbg[6] | ((uint64_t)dbg[7] << 32);
+    out->fast_order = ctx->has_scene ? ctx->S.fast_on : 0u;
+    out->_pad2 = 0;
     std::memcpy(&out->max_leaf_undershoot, &dbg[4], 4);
     HIPCHK(hipMemcpy(out->vote_closest, ctx->d_counters->vote, sizeof(uint64_t) * 18, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out->stack_ops, ctx->d_counters->stk, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));

@@ -218,11 +218,25 @@ PT_DEV float forwarded_bound(const SceneDev& S, V3 o, V3 d, float ct) {
     return (S.fwd_on != 0u && dd >= 0.5f && dd <= 2.0f) ? b : PT_INF;
 }
 
+// ---- FAST mode: nearest child first, with a check that the order could not have mattered ---------------------------
+// The reference's walk order (slot order, LIFO) decides nothing but WHICH of several near-tied hits wins and how much
+// work the walk does.  A closest-hit kernel compiled with FAST pushes a node's hit children far to near, so that the
+// nearest is popped first and closest_t shrinks early, culls an entry only when its distance exceeds
+// closest_t * FAST_CULL + slack, and keeps a flag per level: "another hit lies within closest_t * FAST_BAND + slack of
+// the best one".  A ray that ends with the flag clear has exactly one hit in that band — the reference's walk, whatever
+// its order, can only return that hit (DESIGN.md "Nearest first" gives the argument; it rests on the same measured
+// assumption as forwarded_bound: a computed hit distance does not lie in front of the computed entry distance of a box
+// around it by more than a factor 1 + 2^-10 plus the certified rounding slack).  A ray that ends with the flag set, a
+// NaN-slab ray, a ray outside the certified range of the slack (origin far outside the scene, direction far from unit
+// length) is traced again by the same lane in reference order (`slow`): same kernel, no second launch.
+constexpr float FAST_CULL = 1.00390625f;     // 1 + 2^-8
+constexpr float FAST_BAND = 1.001953125f;    // 1 + 2^-9
+
 enum : uint32_t { ACT_IDLE = 0, ACT_NODE = 1, ACT_TRI = 2, ACT_ENTER = 3, ACT_EXIT = 4, ACT_POP = 5, ACT_DONE = 6 };
 
 // Per-lane traversal state.  The world ray is not kept while a lane is inside an instance: it is re-read from the
 // queue entry when the instance is left; the closest hit is written through the sink when it is accepted.
-template <bool ANY, bool CNT>
+template <bool ANY, bool CNT, bool FAST = false>
 struct Traverser {
     V3 o, d, inv;              // ray of the level being traversed
     float ct;                  // closest_t of that level (ANY: its ray.t_max)
@@ -234,12 +248,15 @@ struct Traverser {
     uint32_t pw;               // NODE: child word; TRI: next TriRec; ENTER: TLAS leaf word; EXIT: marker word
     uint32_t tri_cnt;          // TRI: triangles left in the leaf
     bool in_mesh, found, exact;
+    bool amb_w, amb_l;         // FAST: another hit within the band of the best one, at the world level / inside the current instance
+    bool slow;                 // FAST kernels: this lane walks its ray in reference order (second attempt, or a ray outside the margins' range)
+    PT_DEV bool fast() const { return FAST && !slow; }
     float leaf_dist;           // counted kernels: entry distance of the leaf whose triangles are being tested
     LaneCnt* lcp;              // counted kernels: the lane's counters (visit_child has no other way to them)
 
     // which tree the current level is walked in: the faithful one for NaN-slab rays and for the counted kernels
     PT_DEV bool faithful() const { return CNT || exact; }
-    PT_DEV void begin(const SceneDev& S, V3 origin, V3 direction, float tmax) {
+    PT_DEV void begin(const SceneDev& S, V3 origin, V3 direction, float tmax, bool again = false) {
         o = origin; d = direction;
         inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);          // Ray::new (ray.rs:13-21)
         exact = ray_needs_exact(o, inv);
@@ -252,16 +269,26 @@ struct Traverser {
         // Bvh8::traverse_*: empty => None/false; the root is popped with dist 0.0: culled only if closest_t <= 0
         // (accel/bvh.rs:322-329)
         act = (S.n_tlas_nodes == 0 || (!ANY && 0.0f >= ct)) ? ACT_DONE : ACT_NODE;
+        if (FAST) {
+            amb_l = false; amb_w = false;
+            // outside what the margins are certified for (or a second attempt): reference order
+            const float dd = dot(d, d);
+            slow = again || exact || !(dd >= 0.5f && dd <= 2.0f) || !(((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) <= S.fast_omax);
+        }
     }
+    // FAST: what an entry distance is compared with (pop-time cull, the box test's t_max)
+    PT_DEV float cull_bound(const SceneDev& S) const { return fast() ? ct * S.fast_cull + S.fast_slack : ct; }
+    PT_DEV float band_bound(const SceneDev& S, float best) const { return best * S.fast_band + S.fast_slack; }
 
     // ---- pop entries until one needs work; sets the next action (accel/bvh.rs:322-329) ---------------
-    PT_DEV void pop(const StackRef& st, LaneCnt& lc) {
+    PT_DEV void pop(const SceneDev& S, const StackRef& st, LaneCnt& lc) {
+        const float cb = cull_bound(S);      // closest_t does not change inside pop
         for (;;) {
             if (sp == 0) { act = ACT_DONE; return; }
             --sp;
             if (CNT) { lc.stk_reads++; if (sp >= LDS_STACK) lc.stk_reads_hbm++; }
             const uint2 e = st_read(st, sp);
-            if (!ANY && __uint_as_float(e.y) >= ct) continue;
+            if (!ANY && (fast() ? __uint_as_float(e.y) > cb : __uint_as_float(e.y) >= ct)) continue;
             pw = e.x;
             if (in_mesh) {
                 if (e.y == NEG_INF_BITS) act = ACT_EXIT;       // the marker: mesh level drained
@@ -280,9 +307,9 @@ struct Traverser {
     // One child: the box test (accel/bvh.rs:198-215 for that slot) and, on a hit, the push (do_node has made sure
     // that the stack has room for all of the record's children).
     template <bool EXACT>
-    PT_DEV void visit_child(const StackRef& st, const float4 lo, const float4 hi, bool valid) {
+    PT_DEV void visit_child(const StackRef& st, const float4 lo, const float4 hi, bool valid, float tmax) {
         float te;
-        const bool h = box_test<EXACT>(lo, hi, o, inv, RAY_EPSILON, ct, &te) && valid;
+        const bool h = box_test<EXACT>(lo, hi, o, inv, RAY_EPSILON, tmax, &te) && valid;
         if (h) {
             if (CNT) { lcp->stk_writes++; if (sp >= LDS_STACK) lcp->stk_writes_hbm++; }
             const uint32_t w = __float_as_uint(hi.z);
@@ -293,11 +320,30 @@ struct Traverser {
     // up to four children of one 128-B unit, last first; q0..q5 = children 0..2 of the unit, already in registers
     template <bool EXACT, bool WIDE>
     PT_DEV void visit_unit(const StackRef& st, const float4* q, uint32_t nb, const float4 q0, const float4 q1, const float4 q2,
-                           const float4 q3, const float4 q4, const float4 q5) {
-        if (WIDE && nb > 3u) { const float4 d0 = q[6], d1 = q[7]; visit_child<EXACT>(st, d0, d1, true); }
-        visit_child<EXACT>(st, q4, q5, nb > 2u);
-        visit_child<EXACT>(st, q2, q3, nb > 1u);
-        visit_child<EXACT>(st, q0, q1, true);
+                           const float4 q3, const float4 q4, const float4 q5, float tmax) {
+        if (FAST && !WIDE) {
+            // One code path for both kinds of lane.  The three children start in the reference's push order (last child
+            // first); a nearest-first lane then sorts them far to near, a reference-order lane (`slow`) leaves them
+            // alone.  A miss gets key -1 and is skipped.
+            float t0, t1, t2;
+            const bool h0 = box_test<EXACT>(q0, q1, o, inv, RAY_EPSILON, tmax, &t0);
+            const bool h1 = box_test<EXACT>(q2, q3, o, inv, RAY_EPSILON, tmax, &t1) && nb > 1u;
+            const bool h2 = box_test<EXACT>(q4, q5, o, inv, RAY_EPSILON, tmax, &t2) && nb > 2u;
+            float ka = h2 ? t2 : -1.0f, kb = h1 ? t1 : -1.0f, kc = h0 ? t0 : -1.0f;
+            uint32_t wa = __float_as_uint(q5.z), wb = __float_as_uint(q3.z), wc = __float_as_uint(q1.z);
+            const bool srt = fast();
+            if (srt && ka < kb) { const float tk = ka; ka = kb; kb = tk; const uint32_t tw = wa; wa = wb; wb = tw; }
+            if (srt && kb < kc) { const float tk = kb; kb = kc; kc = tk; const uint32_t tw = wb; wb = wc; wc = tw; }
+            if (srt && ka < kb) { const float tk = ka; ka = kb; kb = tk; const uint32_t tw = wa; wa = wb; wb = tw; }
+            if (ka >= 0.0f) { st_write(st, sp, wa, __float_as_uint(ka)); ++sp; }
+            if (kb >= 0.0f) { st_write(st, sp, wb, __float_as_uint(kb)); ++sp; }
+            if (kc >= 0.0f) { st_write(st, sp, wc, __float_as_uint(kc)); ++sp; }
+            return;
+        }
+        if (WIDE && nb > 3u) { const float4 d0 = q[6], d1 = q[7]; visit_child<EXACT>(st, d0, d1, true, tmax); }
+        visit_child<EXACT>(st, q4, q5, nb > 2u, tmax);
+        visit_child<EXACT>(st, q2, q3, nb > 1u, tmax);
+        visit_child<EXACT>(st, q0, q1, true, tmax);
     }
     // WIDE = false: no lane of this run has a record with more than 3 children (the faithful tree of the reference's
     // builder never has one), so the fourth child and the second unit are compiled out.
@@ -316,18 +362,18 @@ struct Traverser {
             // node action — the lane stays in ACT_NODE with the record's first unit as a 4-child record.  Two short
             // visits instead of one long one keep the kernel at 80 VGPRs; only hosts with truly wide BVH8 nodes (the
             // reference's builder stops at 3 children) and the PTX_WIDE_RAY_BVH experiment reach this.
-            visit_unit<EXACT, true>(st, p + 8, nchild - 4u, r0, r1, r2, r3, r4, r5);
+            visit_unit<EXACT, true>(st, p + 8, nchild - 4u, r0, r1, r2, r3, r4, r5, cull_bound(S));
             pw = (pw & NODE_INDEX_MASK) | (3u << NODE_NCHILD_SHIFT);
             act = ACT_NODE;
         } else {
             if (CNT) { const uint32_t meta = __float_as_uint(r1.w); lc.node_visits += (meta >> 4) & 1u; lc.node_children += meta & 15u; }
-            visit_unit<EXACT, WIDE>(st, p, nchild, r0, r1, r2, r3, r4, r5);
+            visit_unit<EXACT, WIDE>(st, p, nchild, r0, r1, r2, r3, r4, r5, cull_bound(S));
         }
         if (CNT) lc.stack_hw = (uint32_t)sp > lc.stack_hw ? (uint32_t)sp : lc.stack_hw;
     }
 
     // ---- ACT_TRI: intersect_triangle on the next primitive of the leaf ------------------
-    PT_DEV void do_tri(LaneCnt& lc, const float4 ta, const float4 tb, const float4 tc) {
+    PT_DEV void do_tri(const SceneDev& S, LaneCnt& lc, const float4 ta, const float4 tb, const float4 tc) {
         const float tmin = RAY_EPSILON;
         if (CNT) { lc.prim_reads++; lc.tri_tests++; }
         pw += 1u; tri_cnt -= 1u;
@@ -349,6 +395,12 @@ struct Traverser {
         if (hit) {
             if (CNT) { const float us = (leaf_dist - t) / t; lc.undershoot = us > lc.undershoot ? us : lc.undershoot; }
             if (ANY) { found = true; act = ACT_DONE; return; }
+            if (FAST) {
+                // a second hit within the band of the instance's best one: which of them the reference's walk returns depends on its order
+                const bool have = m_tri != PTX_MISS;
+                if (t < ct) amb_l = have && ct <= band_bound(S, t);
+                else if (have && t <= band_bound(S, ct)) amb_l = true;
+            }
             if (t < ct) { ct = t; m_tri = __float_as_uint(tc.y); m_u = u; m_v = v; }
         }
     }
@@ -374,7 +426,12 @@ struct Traverser {
         bool bhit;
         if (__ballot(lexact) != 0ull) bhit = box_test<true>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
         else bhit = box_test<false>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
-        const float bound = (ANY || exact || lexact || (CNT && S.fwd_on < 2u)) ? PT_INF : forwarded_bound(S, o, d, ct);
+        if (fast() && lexact) { amb_w = true; found = false; act = ACT_DONE; return; }      // NaN slabs in the local frame: start over in reference order
+        if (FAST) amb_l = false;
+        // a nearest-first lane must SEE every local hit that could tie with the best one: its bound carries the scene-wide
+        // slack (>= this ray's rounding bound) four times over instead of the per-ray term
+        const float bound = (ANY || exact || lexact || (CNT && S.fwd_on < 2u)) ? PT_INF
+                            : fast() ? ct * 1.03125f + 4.0f * S.fast_slack : forwarded_bound(S, o, d, ct);
         if (!bhit || (!ANY && tb_enter >= bound)) { act = ACT_POP; return; }
         if (CNT) lc.prim_reads++;   // the Blas leaf's own primitive index
         // park the world level under a marker and descend into the mesh BVH
@@ -411,6 +468,13 @@ struct Traverser {
             const V3 local_hit_point = o + ct * d;
             const V3 world_hit_point = xf_point(ma, mb, mc, local_hit_point);
             const float t_world = dot(world_hit_point - wo, wd) / dot(wd, wd);
+            if (FAST) {
+                // this instance's winner against the best so far; a winner that is itself in doubt (amb_l) stands for
+                // hits down to one band below it
+                if (amb_l && t_world <= band_bound(S, band_bound(S, ct_world))) amb_w = true;
+                if (t_world < ct_world) { if (!amb_l) amb_w = found && ct_world <= band_bound(S, t_world); }
+                else if (found && t_world <= band_bound(S, ct_world)) amb_w = true;
+            }
             if (t_world < ct_world) {                               // traverse_closest accept (accel/bvh.rs:353-357)
                 ct_world = t_world;
                 sink.hit(my, cur_inst, m_tri, t_world, m_u, m_v);
@@ -431,15 +495,18 @@ struct Traverser {
 // `Src::fetch(k, o, d, tmax)` loads its ray; `Sink::hit(k, inst, tri, t, u, v)` records an accepted closest hit (the last
 // call for an entry is its result); `Sink::done(k, found)` ends the entry.
 // `work` is the queue's shared cursor, `n` its length.
-template <bool ANY, bool CNT, class Src, class Sink>
+// FAST (closest-hit only): see above.
+template <bool ANY, bool CNT, bool FAST = false, class Src, class Sink>
 PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink,
-                        LaneCnt& lc, uint32_t& nrays, uint32_t* err) {      // err: the device error word (set on a stack overflow)
+                        LaneCnt& lc, uint32_t& nrays, uint32_t* err,       // err: the device error word (set on a stack overflow)
+                        unsigned long long* again_count = nullptr) {            // FAST: statistics, rays traced a second time
     // a short queue cannot feed every wave: the surplus ones leave without touching the cursors (6144 waves bumping
     // a few addresses made an empty launch cost 70 us)
     if ((unsigned long long)blockIdx.x * 16ull >= (unsigned long long)n + 128ull) return;
-    Traverser<ANY, CNT> tv;
+    Traverser<ANY, CNT, FAST> tv;
     tv.act = ACT_IDLE;
-    tv.exact = false; tv.in_mesh = false; tv.found = false;
+    tv.exact = false; tv.in_mesh = false; tv.found = false; tv.amb_w = false; tv.amb_l = false; tv.slow = false;
+    uint32_t n_again = 0;
     tv.sp = 0; tv.pw = 0; tv.tri_cnt = 0; tv.tri_base = 0; tv.m_tri = PTX_MISS; tv.m_u = 0.0f; tv.m_v = 0.0f;
     tv.ct = 0.0f; tv.o = v3(0.0f, 0.0f, 0.0f); tv.d = tv.o; tv.inv = tv.o;
     tv.leaf_dist = 0.0f; tv.lcp = nullptr;
@@ -484,7 +551,16 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
             }
         }
         if (CNT) tv.lcp = &lc;
-        if (tv.act == ACT_POP) tv.pop(st, lc);
+        if (tv.act == ACT_POP) tv.pop(S, st, lc);
+        if (FAST && tv.act == ACT_DONE && tv.amb_w && !tv.slow) {
+            // the result could depend on the walk order: the lane starts its ray over, in reference order (whatever the
+            // first attempt wrote through the sink is overwritten)
+            V3 o, d;
+            float tmax;
+            src.fetch(my, &o, &d, &tmax);
+            tv.begin(S, o, d, tmax, true);
+            n_again++;
+        }
         if (tv.act == ACT_DONE) { sink.done(my, tv.found); tv.act = ACT_IDLE; }
 
         // vote: the action most lanes are waiting for runs, and so does any other with RUN_THRESHOLD lanes waiting
@@ -529,12 +605,17 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
             r0 = p[0]; r1 = p[1]; r2 = p[2];
             if (f_node) { r3 = p[3]; r4 = p[4]; r5 = p[5]; }
         }
-        if (f_tri) tv.do_tri(lc, r0, r1, r2);
+        if (f_tri) tv.do_tri(S, lc, r0, r1, r2);
         if (f_node) {
             if (wave_exact) tv.template do_node<true, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
             else if (wave_wide) tv.template do_node<false, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
             else tv.template do_node<false, false>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
         }
+    }
+    if (FAST && again_count) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) n_again += (uint32_t)__shfl_xor((int)n_again, off);
+        if (lane == 0u && n_again) atomicAdd(again_count, (unsigned long long)n_again);
     }
 }
 

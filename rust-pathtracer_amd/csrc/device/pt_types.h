@@ -138,6 +138,10 @@ struct SceneDev {
     // forwarded_bound (pt_traverse.h): rounding bound of world -> local -> world, certified per scene at upload
     uint32_t fwd_on;
     float fwd_lin, fwd_t;
+    // FAST traversal (pt_traverse.h): rays whose origin has |o|_1 <= fast_omax (the scene's extent) may take it;
+    // fast_slack = the world/local rounding bound at that extent, the absolute part of every FAST margin
+    uint32_t fast_on;
+    float fast_omax, fast_slack, fast_cull, fast_band;     // cull factor 1 + 4m, band factor 1 + 2m
 };
 
 struct CameraDev {
@@ -151,7 +155,7 @@ struct DevCounters {
     unsigned long long v[sizeof(PtxCounters) / 8];
     // PtxDebugStats (not part of PtxCounters): [0] deepest per-ray stack (counted kernels), [1] deepest packet stack,
     // [2..3] rays handed from overflowed packets to k_extend_redo (u64), [4] largest leaf undershoot (f32 bits, counted kernels)
-    unsigned int dbg[6];
+    unsigned int dbg[8];      // ... [6..7] rays the FAST closest-hit kernel handed to the reference-order kernel (u64)
     // the wave vote of the counted per-ray kernels (LaneCnt::vote), closest-hit [0..8] then any-hit [9..17]
     unsigned long long vote[18];
     unsigned long long stk[4];     // counted per-ray kernels: node-visit stack entries read, read from the HBM strips, written, written to the strips

@@ -291,7 +291,7 @@ class HipRenderLoop:
         out = {}
         for n, _ in abi.PtxDebugStats._fields_:
             v = getattr(d, n)
-            if n == "_pad":
+            if n in ("_pad", "_pad2"):
                 continue
             out[n] = float(v) if n == "max_leaf_undershoot" else ([int(x) for x in v] if n.startswith("vote_") or n == "stack_ops" else int(v))
         return out

@@ -350,3 +350,35 @@ def test_side_stream_overlap_changes_nothing(pkg, oracle_det, full_scenes, monke
     for a, b in zip(frames[0], frames[1]):
         assert np.array_equal(bits(a), bits(b))
     assert np.array_equal(bits(frames[0][3]), bits(oracle_det.scene(sc).render_pass(cam, w, h, 2, bounces)))
+
+
+def test_nearest_first_equals_reference_order_on_the_full_scenes(pkg, loop, oracle_det, full_scenes, monkeypatch):
+    """FAST mode (nearest child first + the second attempt in reference order for rays with a near-tied second hit) on
+    by default: hit records and frames must equal both the oracle's and the same kernels with PTX_EXACT_ORDER=1; the
+    share of rays that needed the second attempt is printed (1.4 % of the Bistro-like scene's bounce rays)."""
+    abi = pkg._abi
+    monkeypatch.setenv("PTX_EXACT_ORDER", "1")
+    lp_ref = pkg.HipRenderLoop(0)
+    for name in FULL:
+        sc = full_scenes(name)
+        w, h = 400, 225
+        cam = sc.default_camera(w / h)
+        osc = oracle_det.scene(sc)
+        prim = osc.primary_rays(cam, w, h, 13)
+        sec = secondary_rays(abi, osc, prim, osc.trace_closest(prim), 31)
+        want = osc.trace_closest(sec)
+        ref = lp_ref.trace_closest(sc, sec)                  # uploads with the switch set
+        assert lp_ref.debug_stats()["fast_order"] == 0
+        monkeypatch.delenv("PTX_EXACT_ORDER")
+        loop._scene = None
+        loop.reset_counters()
+        got = loop.trace_closest(sc, sec)
+        dbg = loop.debug_stats()
+        monkeypatch.setenv("PTX_EXACT_ORDER", "1")
+        assert dbg["fast_order"] == 1, name
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)) and np.array_equal(ref.view(np.uint8), want.view(np.uint8)), name
+        print(f"\n[{name}] {len(sec)} bounce rays and segments: {dbg['fast_redo_rays']} second attempts ({dbg['fast_redo_rays'] / len(sec):.2%})")
+        assert dbg["fast_redo_rays"] < 0.2 * len(sec), dbg
+        img = osc.render_pass(cam, 160, 90, 6, FULL[name][1])
+        assert np.array_equal(bits(loop.render_pass(sc, cam, pkg.PathTracer(FULL[name][1]), 160, 90, 6)), bits(img)), name
+        assert np.array_equal(bits(lp_ref.render_pass(sc, cam, pkg.PathTracer(FULL[name][1]), 160, 90, 6)), bits(img)), name

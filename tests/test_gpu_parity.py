@@ -894,3 +894,64 @@ def test_forwarded_bound_with_hard_instance_transforms(pkg, loop, oracle_det, mo
     got2 = loop.trace_closest(sc2, rays2)
     assert loop.debug_stats()["bound_forwarding"] == 0
     assert np.array_equal(got2.view(np.uint8), osc2.trace_closest(rays2).view(np.uint8))
+
+
+def test_nearest_first_walk_with_near_coincident_surfaces(pkg, loop, oracle_det, monkeypatch):
+    """The closest-hit kernels walk nearest child first and hand a ray back to the reference order only when a second
+    hit lies within a small band of the best one (csrc/device/pt_traverse.h "FAST mode").  Here most rays have such
+    a second hit: one mesh holds stacked copies of a grid — exact duplicates (ties the reference settles by its walk
+    order), copies 1e-6, 3e-4, 2e-3 and 5e-2 above — with its triangles shuffled, instanced three times so that
+    surfaces of different instances nearly coincide as well.  Every hit must be the oracle's, and the kernel must
+    report that it took the second road."""
+    abi = pkg._abi
+    rng = np.random.default_rng(11)
+    n = 9
+    gx, gz = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n), indexing="ij")
+    layers = [0.0, 0.0, 1e-6, 3e-4, 2e-3, 5e-2]
+    pos, idx = [], []
+    for y in layers:
+        base = len(pos)
+        pos += [(float(x), y, float(z)) for x, z in zip(gx.ravel(), gz.ravel())]
+        for i in range(n - 1):
+            for j in range(n - 1):
+                a, b, c, d = base + i * n + j, base + (i + 1) * n + j, base + (i + 1) * n + j + 1, base + i * n + j + 1
+                idx += [(a, b, c), (a, c, d)]
+    idx = np.array(idx, dtype=np.uint32)[rng.permutation(len(idx))]
+    pos = np.array(pos, dtype=np.float32)
+    b = pkg.SceneBuilder()
+    b.add_material(pkg.default_material())
+    mesh = b.add_mesh(pos, idx)
+    transforms = [np.eye(4), _affine(np.eye(3), (0.0, 1e-4, 0.0)), _affine(_rot((0, 1, 0), 0.5) * 1.5, (0.1, -2e-4, 0.0)),
+                  _affine(_rot((1, 0, 0), 0.3), (0.0, 0.02, 0.3))]
+    for t in transforms:
+        b.add_instance(mesh, np.asarray(t, dtype=np.float32))
+    b.set_sky_solid(0.5, 0.6, 0.8)
+    sc = b.build()
+    osc = oracle_det.scene(sc)
+    m = 60000
+    target = np.stack([rng.uniform(-1.2, 1.2, m), rng.uniform(-0.01, 0.06, m), rng.uniform(-1.2, 1.2, m)], axis=1)
+    origin = target + rng.normal(size=(m, 3)) * rng.choice([0.05, 0.5, 3.0], size=(m, 1))
+    d = target - origin
+    dist = np.linalg.norm(d, axis=1, keepdims=True)
+    d /= dist
+    rays = np.zeros(m, dtype=abi.ray_dtype())
+    rays["origin"], rays["direction"] = origin.astype(np.float32), d.astype(np.float32)
+    rays["t_max"] = np.where(rng.uniform(size=m) < 0.6, np.inf, dist[:, 0] * rng.uniform(0.97, 1.03, m)).astype(np.float32)
+    want = osc.trace_closest(rays)
+    assert (want["inst_idx"] != abi.PTX_MISS).mean() > 0.3
+    loop.reset_counters()
+    got = loop.trace_closest(sc, rays)
+    dbg = loop.debug_stats()
+    bad = np.flatnonzero((got.view(np.uint8).reshape(m, -1) != want.view(np.uint8).reshape(m, -1)).any(axis=1))
+    assert len(bad) == 0, (len(bad), rays[bad[:3]], got[bad[:3]], want[bad[:3]])
+    assert dbg["fast_order"] == 1 and dbg["fast_redo_rays"] > 0.2 * m, dbg
+    assert np.array_equal(loop.trace_any(sc, rays), osc.trace_any(rays))
+    # a frame through the integrator (bounce rays start ON these surfaces), and the same with the reference order forced
+    cam = pkg.Camera.look_at((0.3, 1.5, 2.5), (0.0, 0.0, 0.0), 50.0, 16 / 9)
+    img = osc.render_pass(cam, 128, 72, 0, 6)
+    assert np.array_equal(bits(loop.render_pass(sc, cam, pkg.PathTracer(6), 128, 72, 0)), bits(img))
+    monkeypatch.setenv("PTX_EXACT_ORDER", "1")
+    lp = pkg.HipRenderLoop(0)
+    assert np.array_equal(lp.trace_closest(sc, rays).view(np.uint8), want.view(np.uint8))
+    assert lp.debug_stats()["fast_order"] == 0
+    assert np.array_equal(bits(lp.render_pass(sc, cam, pkg.PathTracer(6), 128, 72, 0)), bits(img))
