@@ -229,7 +229,8 @@ def main():
     if os.path.exists(lim_file):
         try:
             lim = json.load(open(lim_file))
-            k = lim.get("kernels", {}).get("k_extend<false>")
+            kernels = lim.get("kernels", {})
+            k = kernels.get("k_extend<false, true>") or kernels.get("k_extend<false, false>") or kernels.get("k_extend<false>")   # nearest-first / reference-order instantiation
             if lim.get("config") == this_config and k:
                 roofline["traffic"] = k["hbm_bytes_per_launch"]
                 # counter bytes over THIS run's launch time
