@@ -1729,7 +1729,9 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
             } else {
                 const bool fast = ctx->S.fast_on != 0u && !ctx->counting;
                 ScopedEvent ev(ctx, CLS_EXTEND);
-                if (ctx->counting) hipLaunchKernelGGL((k_extend<true, false>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                if (ctx->counting && ctx->S.fwd_on == 2u && ctx->S.fast_on)      // PTX_COUNT_FORWARD=1 (measurement only): count what the shipped walk does
+                    hipLaunchKernelGGL((k_extend<true, true>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                else if (ctx->counting) hipLaunchKernelGGL((k_extend<true, false>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
                 else if (fast) hipLaunchKernelGGL((k_extend<false, true>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
                 else hipLaunchKernelGGL((k_extend<false, false>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
             }
@@ -2139,7 +2141,7 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
             omax = 2.0 * omax + 1.0;
             const double slack = 1.5 * (lin * omax + tr) * 1.0000002;
             const char* exact_order = std::getenv("PTX_EXACT_ORDER");
-            S.fast_on = (S.fwd_on == 1u && omax < 1e30 && slack < 1e30 && !(exact_order && exact_order[0] == '1')) ? 1u : 0u;
+            S.fast_on = (S.fwd_on != 0u && omax < 1e30 && slack < 1e30 && !(exact_order && exact_order[0] == '1')) ? 1u : 0u;
             S.fast_omax = (float)omax; S.fast_slack = (float)slack;
             S.fast_cull = FAST_CULL; S.fast_band = FAST_BAND;
             if (std::getenv("PTX_VERBOSE")) fprintf(stderr, "[ptx] forwarding %u (lin %.3g, tr %.3g); nearest-first %u (|o|_1 <= %.4g, slack %.3g)\n", S.fwd_on, lin, tr, S.fast_on, omax, slack);

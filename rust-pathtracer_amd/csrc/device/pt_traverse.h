@@ -288,7 +288,7 @@ struct Traverser {
             --sp;
             if (CNT) { lc.stk_reads++; if (sp >= LDS_STACK) lc.stk_reads_hbm++; }
             const uint2 e = st_read(st, sp);
-            if (!ANY && (fast() ? __uint_as_float(e.y) > cb : __uint_as_float(e.y) >= ct)) continue;
+            if (!ANY && __uint_as_float(e.y) >= cb) continue;      // cb == closest_t for a reference-order walk (accel/bvh.rs:327-329)
             pw = e.x;
             if (in_mesh) {
                 if (e.y == NEG_INF_BITS) act = ACT_EXIT;       // the marker: mesh level drained
@@ -332,9 +332,18 @@ struct Traverser {
             float ka = h2 ? t2 : -1.0f, kb = h1 ? t1 : -1.0f, kc = h0 ? t0 : -1.0f;
             uint32_t wa = __float_as_uint(q5.z), wb = __float_as_uint(q3.z), wc = __float_as_uint(q1.z);
             const bool srt = fast();
-            if (srt && ka < kb) { const float tk = ka; ka = kb; kb = tk; const uint32_t tw = wa; wa = wb; wb = tw; }
-            if (srt && kb < kc) { const float tk = kb; kb = kc; kc = tk; const uint32_t tw = wb; wb = wc; wc = tw; }
-            if (srt && ka < kb) { const float tk = ka; ka = kb; kb = tk; const uint32_t tw = wa; wa = wb; wb = tw; }
+            // three compare-swaps as selects (no branches: exec-mask bookkeeping would cost more than the moves)
+            {
+                const bool s1 = srt && ka < kb;
+                const float xa = s1 ? kb : ka, xb = s1 ? ka : kb; const uint32_t ya = s1 ? wb : wa, yb = s1 ? wa : wb;
+                ka = xa; kb = xb; wa = ya; wb = yb;
+                const bool s2 = srt && kb < kc;
+                const float xb2 = s2 ? kc : kb, xc2 = s2 ? kb : kc; const uint32_t yb2 = s2 ? wc : wb, yc2 = s2 ? wb : wc;
+                kb = xb2; kc = xc2; wb = yb2; wc = yc2;
+                const bool s3 = srt && ka < kb;
+                const float xa3 = s3 ? kb : ka, xb3 = s3 ? ka : kb; const uint32_t ya3 = s3 ? wb : wa, yb3 = s3 ? wa : wb;
+                ka = xa3; kb = xb3; wa = ya3; wb = yb3;
+            }
             if (ka >= 0.0f) { st_write(st, sp, wa, __float_as_uint(ka)); ++sp; }
             if (kb >= 0.0f) { st_write(st, sp, wb, __float_as_uint(kb)); ++sp; }
             if (kc >= 0.0f) { st_write(st, sp, wc, __float_as_uint(kc)); ++sp; }
