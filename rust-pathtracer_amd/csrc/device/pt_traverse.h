@@ -26,6 +26,11 @@
 // sit the iteration out.  Each action body loads its own record, so a lane
 // carries no prefetch registers and the kernel fits more waves per SIMD.
 //
+// Two ways to walk.  The reference-order walk below reproduces the reference's visit order exactly; it is what the
+// counted kernels, the any-hit kernels, the packets and every second attempt run.  The uncounted closest-hit kernels
+// walk nearest child first ("FAST mode" further down) and fall back to the reference order, ray by ray, whenever the
+// order could decide the result.
+//
 // Order is preserved exactly through the unified stack:
 //   * a record lists its children in the order the reference's walk takes them
 //     (leaf slots ascending, then internal slots descending: pt_types.h); a node
