@@ -134,6 +134,7 @@ def main():
     frame()
     fence()
     cnt = loop.counters()
+    dbg_counted = loop.debug_stats()      # max_leaf_undershoot over every triangle hit of the counted frame: the margins' presumption, measured
     # the same frame cut after its primary rays (PathTracer<1>): the closest-hit events of the first extend launch,
     # which the timed frames trace with the packet kernel; the per-ray kernel's bytes are the rest
     loop.reset_counters()
@@ -188,6 +189,16 @@ def main():
         "mean_radiance": round(float(s_sum.sum(dtype=np.float64)) / max(1, n_owned * spp * 3), 6),
         "sum_sha256_16": __import__("hashlib").sha256(s_sum.tobytes()).hexdigest()[:16],
     }
+    # what the forwarded bound and the nearest-first walk presume, measured on this run: how far a computed
+    # triangle hit lay in front of its leaf box at most (counted frame, relative), and how many closest-hit rays of the
+    # timed frames were traced a second time in reference order
+    dbg_timed = loop.debug_stats()
+    verify["max_leaf_undershoot"] = float(f"{dbg_counted['max_leaf_undershoot']:.3e}")
+    verify["max_leaf_undershoot_beyond_slack"] = float(f"{dbg_counted['max_leaf_undershoot_excess']:.3e}")
+    verify["undershoot_tolerated"] = {"forwarded_bound": 2.0 ** -5, "nearest_first": 2.0 ** -10}
+    verify["bound_forwarding"] = int(dbg_timed["bound_forwarding"])
+    verify["nearest_first"] = int(dbg_timed["fast_order"])
+    verify["second_attempt_rays_per_frame"] = int(dbg_timed["fast_redo_rays"] // max(1, args.steps + args.warmup))
     if not (verify["counts_eq_spp"] and verify["finite"] and verify["clamped"]):
         raise SystemExit(f"bench.py: the timed frame failed its own checks: {verify}")
 

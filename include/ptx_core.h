@@ -421,7 +421,7 @@ typedef struct PtxDebugStats {
     uint32_t lds_stack_entries, packet_lds_entries, packet_capacity;
     float max_leaf_undershoot;   /* counted kernels: largest (t_enter(leaf box) - t) / t over all triangle hits computed */
     uint32_t bound_forwarding;   /* 1 = closest-hit rays take the world closest_t into instances, 0 = off for this scene */
-    uint32_t _pad;
+    float max_leaf_undershoot_excess;   /* the same with the scene's absolute slack taken off first: (t_enter - t - slack) / t, 0 if never positive; what the relative margins must cover */
     /* The wave vote of the counted per-ray kernels since ptx_reset_counters: [0] loop iterations summed over waves,
      * [1..4] iterations in which the NODE / TRI / ENTER / EXIT action ran, [5..8] lanes that took part in it. */
     uint64_t vote_closest[9];

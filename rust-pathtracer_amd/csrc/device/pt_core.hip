@@ -165,6 +165,10 @@ PT_DEV void flush_lane_cnt(DevCounters* dc, const LaneCnt& lc, uint32_t rays, bo
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(us, off); us = o > us ? o : us; }
       if ((threadIdx.x & 63u) == 0u && us > 0.0f) atomicMax(&dc->dbg[4], __float_as_uint(us)); }
+    { float us = lc.undershoot_x;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(us, off); us = o > us ? o : us; }
+      if ((threadIdx.x & 63u) == 0u && us > 0.0f) atomicMax(&dc->dbg[5], __float_as_uint(us)); }
     if ((threadIdx.x & 63u) == 0u)
         for (int k = 0; k < 9; ++k) atomicAdd(&dc->vote[(any ? 9 : 0) + k], (unsigned long long)lc.vote[k]);
     wave_add(&dc->stk[0], lc.stk_reads); wave_add(&dc->stk[1], lc.stk_reads_hbm);
@@ -207,7 +211,7 @@ template <bool ANY, bool CNT, bool FAST = false>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
                                                              uint8_t* out_any, uint32_t* work, uint2* ovf, DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, 0.0f};
     uint32_t nrays = 0;
     BatchSrc src{rays};
     BatchSink<ANY> sink{out_hits, out_any};
@@ -285,7 +289,7 @@ template <bool CNT, bool FAST = false>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S, PathArrays P, const uint32_t* q, const uint32_t* q_walk, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, 0.0f};
     uint32_t nrays = 0;
     const uint32_t n_active = ctr->n_active, n_walk = ctr->n_walk;
     ExtendSrc src{P, q, n_active, q_walk};
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_PACKET_ATTR void k_extend_packet(Sc
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend_redo(SceneDev S, PathArrays P, const uint32_t* q, IterCtr* ctr, uint2* ovf,
                                                              DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, 0.0f};
     uint32_t nrays = 0;
     ExtendSrc src{P, q};
     ExtendSink sink{P};
@@ -360,7 +364,7 @@ template <bool CNT>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_SHADOW_ATTR void k_shadow(SceneDev S, PathArrays P, const uint32_t* qs, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
-    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0};
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, 0.0f};
     uint32_t nrays = 0;
     ShadowSrc src{S, P, qs};
     ShadowSink sink{P};
@@ -2706,7 +2710,7 @@ int32_t ptx_get_debug_stats(PtxContext* ctx, PtxDebugStats* out) {
     HIPCHK(hipMemcpy(out->vote_closest, ctx->d_counters->vote, sizeof(uint64_t) * 18, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out->stack_ops, ctx->d_counters->stk, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
     out->bound_forwarding = ctx->has_scene ? ctx->S.fwd_on : 0u;
-    out->_pad = 0;
+    std::memcpy(&out->max_leaf_undershoot_excess, &dbg[5], 4);
     out->trace_stack_high_water = dbg[0];
     out->packet_stack_high_water = dbg[1];
     out->packet_redo_rays = (uint64_t)dbg[2] | ((uint64_t)dbg[3] << 32);

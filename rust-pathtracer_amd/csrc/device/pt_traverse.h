@@ -166,7 +166,7 @@ PT_DEV uint2 st_read(const StackRef& s, int i) {
 // vote[0] = loop iterations of this wave, vote[1..4] = iterations in which the NODE / TRI / ENTER / EXIT action ran,
 // vote[5..8] = lanes that took part in it (wave-uniform values; lane 0's copy is flushed)
 struct LaneCnt { uint32_t node_visits, node_children, prim_reads, tri_tests, inst_entries, inst_hits, stack_hw; float undershoot; uint32_t vote[9];
-                 uint32_t stk_reads, stk_reads_hbm, stk_writes, stk_writes_hbm; };   // per lane: stack entries read / written, and those in the HBM strip
+                 uint32_t stk_reads, stk_reads_hbm, stk_writes, stk_writes_hbm; float undershoot_x; };   // per lane: stack entries read / written, and those in the HBM strip
 
 PT_DEV V3 xf_point(const float4 a, const float4 b, const float4 c, V3 p) {
     // Mat4::transform_point3: ((x_axis*x + y_axis*y) + z_axis*z) + w_axis, packed columns
@@ -407,7 +407,11 @@ struct Traverser {
         const bool hit = !(fabsf(a) < 1e-8f) && (u >= 0.0f && u <= 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
                          (t >= tmin && t <= PT_INF);   // local ray: t_max = +inf
         if (hit) {
-            if (CNT) { const float us = (leaf_dist - t) / t; lc.undershoot = us > lc.undershoot ? us : lc.undershoot; }
+            if (CNT) {
+                const float us = (leaf_dist - t) / t; lc.undershoot = us > lc.undershoot ? us : lc.undershoot;
+                // ... and what of it the absolute slack of the margins does not cover (the relative part they must)
+                const float ux = ((leaf_dist - t) - S.fast_slack) / t; lc.undershoot_x = ux > lc.undershoot_x ? ux : lc.undershoot_x;
+            }
             if (ANY) { found = true; act = ACT_DONE; return; }
             if (FAST) {
                 // a second hit within the band of the instance's best one: which of them the reference's walk returns depends on its order

@@ -293,7 +293,7 @@ class HipRenderLoop:
             v = getattr(d, n)
             if n in ("_pad", "_pad2"):
                 continue
-            out[n] = float(v) if n == "max_leaf_undershoot" else ([int(x) for x in v] if n.startswith("vote_") or n == "stack_ops" else int(v))
+            out[n] = float(v) if n.startswith("max_leaf_undershoot") else ([int(x) for x in v] if n.startswith("vote_") or n == "stack_ops" else int(v))
         return out
 
     def set_profiling(self, on):

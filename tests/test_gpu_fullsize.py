@@ -325,6 +325,7 @@ def test_forwarded_bound_changes_no_hit_and_hits_sit_inside_their_boxes(pkg, loo
         loop.set_counting(False)
         print(f"\n[{name}] {len(rays)} rays: largest (t_enter(leaf) - t) / t over all triangle hits = {dbg['max_leaf_undershoot']:.3e}")
         assert 0.0 <= dbg["max_leaf_undershoot"] < 2.0 ** -9, (name, dbg)
+        assert dbg["max_leaf_undershoot_excess"] < 2.0 ** -13, (name, dbg)      # beyond the scene's absolute slack: what the nearest-first walk's 2^-10 must cover
         img = osc.render_pass(cam, 160, 90, 4, FULL[name][1])
         assert np.array_equal(bits(loop.render_pass(sc, cam, pkg.PathTracer(FULL[name][1]), 160, 90, 4)), bits(img)), name
 
