@@ -429,8 +429,8 @@ typedef struct PtxDebugStats {
     /* counted per-ray kernels: stack entries popped, popped from the per-lane HBM strips (index >= lds_stack_entries),
      * children pushed, pushed to the strips */
     uint64_t stack_ops[4];
-    /* rays the nearest-first closest-hit kernel handed to the reference-order kernel because their result could depend
-     * on the walk order (DESIGN.md "Nearest first"); fast_order: 1 = that kernel is in use for this scene */
+    /* rays the nearest-first closest-hit kernels traced a second time, in reference order, because their result could
+     * depend on the walk order (DESIGN.md "Nearest first"); fast_order: 1 = those kernels are in use for this scene */
     uint64_t fast_redo_rays;
     uint32_t fast_order, _pad2;
 } PtxDebugStats;
