@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-order-check", action="store_true")   # skip the untimed reference-order frame (kernel experiments only)
     # one-GPU prediction of an N-GPU frame: render every rank's tile partition in turn on this card (no collective)
     ap.add_argument("--emulate-world", type=int, default=0)
     ap.add_argument("--adaptive-cap", type=int, default=0)  # with --emulate-world: adaptive phase up to this many spp (BASELINE config 5: 256)
@@ -128,30 +129,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # counted frame (untimed; counted kernels are slower): rays and algorithmic bytes per frame
-    loop.set_counting(True)
-    loop.reset_counters()
-    frame()
-    fence()
-    cnt = loop.counters()
+    # counted frames (untimed; counted kernels are slower): rays and algorithmic bytes per frame.
+    #   mode 1: the counted kernels walk exactly as the reference does -> the REFERENCE's events (equal the oracle's);
+    #   mode 2: the closest-hit launches walk as the timed kernels do (forwarded bound, nearest child first, second
+    #           attempts included) -> the events the TIMED per-ray kernel executes: the roofline numerator.
+    # Each also cut after its primary rays (PathTracer<1>): the closest-hit events of the first extend launch, which the
+    # timed frames trace with the packet kernel; the per-ray kernel's bytes are the rest.
+    def counted(mode, r=None):
+        loop.set_counting(mode)
+        loop.reset_counters()
+        frame(r)
+        fence()
+        c = loop.counters()
+        if world > 1:
+            keys = sorted(c)
+            t = torch.tensor([c[k] for k in keys], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t)
+            c = {k: int(v) for k, v in zip(keys, t.tolist())}
+        return c
+
+    cnt = counted(1)
     dbg_counted = loop.debug_stats()      # max_leaf_undershoot over every triangle hit of the counted frame: the margins' presumption, measured
-    # the same frame cut after its primary rays (PathTracer<1>): the closest-hit events of the first extend launch,
-    # which the timed frames trace with the packet kernel; the per-ray kernel's bytes are the rest
-    loop.reset_counters()
-    frame(pkg.PathTracer(1))
-    fence()
-    cnt_primary = loop.counters()
-    loop.set_counting(False)
+    cnt_primary = counted(1, pkg.PathTracer(1))
+    cnt_ship = counted(2)
+    cnt_ship_primary = counted(2, pkg.PathTracer(1))
+    loop.set_counting(0)
     note("counted frames done")
-    if world > 1:
-        keys = sorted(cnt)
-        t = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t)
-        cnt = {k: int(v) for k, v in zip(keys, t.tolist())}
-        t = torch.tensor([cnt_primary[k] for k in keys], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t)
-        cnt_primary = {k: int(v) for k, v in zip(keys, t.tolist())}
-        note("counters reduced")
 
     for _ in range(args.warmup):
         frame()
@@ -199,14 +202,53 @@ def main():
     verify["bound_forwarding"] = int(dbg_timed["bound_forwarding"])
     verify["nearest_first"] = int(dbg_timed["fast_order"])
     verify["second_attempt_rays_per_frame"] = int(dbg_timed["fast_redo_rays"] // max(1, args.steps + args.warmup))
+    verify["uncertified_meshes"] = int(dbg_timed["uncertified_meshes"])
     if not (verify["counts_eq_spp"] and verify["finite"] and verify["clamped"]):
         raise SystemExit(f"bench.py: the timed frame failed its own checks: {verify}")
+    # The timed kernels take two shortcuts the reference's walk does not (forwarded bound, nearest child first).  One
+    # more UNTIMED frame in a second context that takes neither (PTX_EXACT_ORDER=1 PTX_NO_FORWARD=1: the reference's
+    # walk operation for operation) must give the same sums bit for bit, or no number is printed.
+    if not args.no_order_check:
+        saved = {k: os.environ.get(k) for k in ("PTX_EXACT_ORDER", "PTX_NO_FORWARD")}
+        os.environ["PTX_EXACT_ORDER"] = "1"
+        os.environ["PTX_NO_FORWARD"] = "1"
+        try:
+            loop2 = pkg.HipRenderLoop(local_rank)
+            loop2.set_partition(rank, world)
+            fb2 = pkg.DeviceFramebuffer(loop2, w, h, adaptive=True)
+            fb2.reset()
+            fb2.render_passes(scene, cam, renderer, 0, spp)
+            loop2.sync()
+            r_sum, r_sq, r_cnt = fb2.read()
+            dbg2 = loop2.debug_stats()
+            loop2.close()
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        mine = r_cnt > 0                  # this rank's own tiles (the timed framebuffer holds every rank's after the exchange)
+        same = bool(dbg2["fast_order"] == 0 and dbg2["bound_forwarding"] == 0 and int(mine.sum()) > 0 and
+                    np.array_equal(s_sum[mine].view(np.uint32), r_sum[mine].view(np.uint32)) and
+                    np.array_equal(s_sq[mine].view(np.uint32), r_sq[mine].view(np.uint32)) and np.array_equal(s_cnt[mine], r_cnt[mine]))
+        if world > 1:
+            t = torch.tensor([1 if same else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            same = bool(t.item())
+        verify["equals_reference_order"] = same
+        verify["reference_order_sum_sha256_16"] = __import__("hashlib").sha256(r_sum.tobytes()).hexdigest()[:16] if world == 1 else None
+        if not same:
+            raise SystemExit(f"bench.py: the timed frame differs from the reference-order frame (PTX_EXACT_ORDER=1 PTX_NO_FORWARD=1): {verify}")
+        note("reference-order frame equals the timed frame")
 
     sec_per_frame = elapsed / args.steps
     rays_per_frame = cnt["rays_closest"] + cnt["rays_any"]
     primary_per_frame = w * h * spp
     mrays = rays_per_frame / sec_per_frame / 1e6
-    abytes_frame = pkg._abi.algorithmic_bytes(cnt, texel_bytes_per_lookup=48, adaptive=True)
+    # algorithmic bytes (SURVEY 8d formula) of the frame: with the timed walk's own traversal events, and with the reference's
+    abytes_frame = pkg._abi.algorithmic_bytes(cnt_ship, texel_bytes_per_lookup=48, adaptive=True)
+    abytes_frame_ref = pkg._abi.algorithmic_bytes(cnt, texel_bytes_per_lookup=48, adaptive=True)
 
     # roofline of the dominant kernel (k_extend), rank 0's launches, HIP events on the library stream
     ext_launches = max(1, tim["extend_launches"])
@@ -214,24 +256,34 @@ def main():
     # k_extend's launches are every iteration but those traced as packets (the primary rays, k_extend_packet):
     # its bytes are the frame's closest-hit bytes minus the primary launch's
     pk_launches = int(tim["packet_launches"])
-    per_ray_bytes = extend_bytes(cnt) - (extend_bytes(cnt_primary) if pk_launches else 0)
+    per_ray_bytes = extend_bytes(cnt_ship) - (extend_bytes(cnt_ship_primary) if pk_launches else 0)
+    per_ray_bytes_ref = extend_bytes(cnt) - (extend_bytes(cnt_primary) if pk_launches else 0)
     # rank 0 traced 1/world of the frame's extend work (tile interleave): per-launch bytes on this rank
     ext_bytes_launch = per_ray_bytes / world * args.steps / ext_launches
+    ext_bytes_launch_ref = per_ray_bytes_ref / world * args.steps / ext_launches
     achieved = ext_bytes_launch / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-    # `achieved` / `frac` are the SURVEY §8(d) contract: the REFERENCE's byte stream (every ray charged for every record
-    # it touches) over the measured launch time.  L1/L2 serve most of that stream, so it is not HBM utilisation:
-    # `traffic` / `measured_hbm_frac` (PMC counters) are, and `limiters` names what actually binds the kernel.
-    roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    achieved_ref = ext_bytes_launch_ref / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+    # `achieved` / `frac`: the SURVEY 8(d) byte formula applied to the events the TIMED kernel executes (its own node visits,
+    # child boxes, triangle tests, instance entries: ptx_set_counting(2)), over its measured launch time.  Every ray is
+    # charged for every record it touches; L1/L2 serve most of that stream, so this is the kernel's record-stream rate
+    # against the HBM peak, not HBM utilisation: `traffic` / `measured_hbm_frac` (PMC counters) are that, and
+    # `binding_limiter` names what actually limits the kernel.
+    roofline = {"bound": "hbm", "kernel": "k_extend<false, true>" if verify["nearest_first"] else "k_extend<false, false>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "measured_hbm_frac": None,
-                "frac_meaning": "algorithmic (reference byte stream, SURVEY 8d: what the reference's walk touches, from the counted kernels) bytes / launch time / 8 TB/s; NOT HBM utilisation and can exceed 1: caches serve most of the stream and the timed kernels skip part of it (forwarded bound). See measured_hbm_frac and limiters",
+                "frac_meaning": "SURVEY 8d bytes of the events the timed kernel itself executes (counted instantiation of the same walk: forwarded bound, nearest child first, second attempts) / launch time / 8 TB/s; caches serve most of this stream, see measured_hbm_frac (PMC) for HBM utilisation and binding_limiter for what binds",
                 "algorithmic_bytes_per_launch": round(ext_bytes_launch), "avg_launch_ms": round(ext_ms, 4),
-                "launches": int(ext_launches)}
+                "launches": int(ext_launches),
+                # secondary: the same launches priced with the REFERENCE's walk (what round 2 reported as frac; can exceed 1
+                # because the timed kernel skips part of that walk)
+                "reference_stream": {"algorithmic_bytes_per_launch": round(ext_bytes_launch_ref), "achieved": round(achieved_ref, 2),
+                                     "frac": round(achieved_ref / HBM_PEAK_GBS, 5)}}
     if pk_launches:
         pk_ms = tim["packet_ms"] / pk_launches
-        pk_bytes = extend_bytes(cnt_primary) / world * args.steps / pk_launches
+        pk_bytes = extend_bytes(cnt_primary) / world * args.steps / pk_launches      # reference stream: the packet kernel has no counted form
         roofline["primary_packets"] = {"kernel": "k_extend_packet", "launches": pk_launches, "avg_launch_ms": round(pk_ms, 4),
                                        "algorithmic_bytes_per_launch": round(pk_bytes),
-                                       "achieved": round(pk_bytes / (pk_ms * 1e-3) / 1e9, 2), "unit": "GB/s"}
+                                       "achieved": round(pk_bytes / (pk_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                                       "note": "reference byte stream of the primary rays (one record fetch serves the 64 rays of a packet: not comparable with the HBM peak)"}
     # PMC-derived figures come from the committed profile of ONE configuration: attach them only when this run is that
     # configuration (otherwise a Cornell run would carry Bistro's traffic)
     this_config = {"scene": args.scene, "detail": args.detail, "width": w, "height": h, "spp": spp, "bounces": args.bounces,
@@ -264,8 +316,10 @@ def main():
         "sec_per_frame": round(sec_per_frame, 4),
         "mprimary_per_s": round(primary_per_frame / sec_per_frame / 1e6, 2),
         "rays_per_frame": rays_per_frame,
-        "algorithmic_bytes_per_frame": abytes_frame,
-        "frame_reference_stream_frac": round(abytes_frame / sec_per_frame / 1e9 / HBM_PEAK_GBS, 5),   # reference byte stream / 8 TB/s: can exceed 1 (caches)
+        "algorithmic_bytes_per_frame": abytes_frame,                 # timed walk's own events (primary rays priced as the per-ray walk would take them)
+        "frame_stream_frac": round(abytes_frame / sec_per_frame / 1e9 / HBM_PEAK_GBS, 5),              # cross-check: bytes per step / ms_per_step / 8 TB/s
+        "reference_algorithmic_bytes_per_frame": abytes_frame_ref,   # the reference's walk of the same frame
+        "frame_reference_stream_frac": round(abytes_frame_ref / sec_per_frame / 1e9 / HBM_PEAK_GBS, 5),   # can exceed 1: the timed kernels skip part of that walk
         "kernel_ms_per_frame": {k: round(tim[k] / args.steps, 3) for k in
                                 ("raygen_ms", "packet_ms", "extend_ms", "shade_ms", "shadow_ms", "accumulate_ms")},
         "kernel_ms_note": ("HIP-event time per kernel class. shadow_ms and accumulate_ms are launched on the library's side stream beside the next "

@@ -405,7 +405,11 @@ int32_t ptx_generate_primary_rays(PtxContext* ctx, uint32_t width, uint32_t heig
  * device, so tests can pin them against glibc and against the oracle. */
 int32_t ptx_debug_math(PtxContext* ctx, int32_t fn, const float* x, const float* y, uint64_t n, float* out);
 
-int32_t ptx_set_counting(PtxContext* ctx, int32_t enabled);   /* counted kernels are slower */
+/* enabled: 0 = off; 1 = the counted kernels walk exactly as the reference does (no forwarded bound, reference order:
+ * the events are the reference's own, accel/bvh.rs:308-415, and equal the oracle's); 2 = the closest-hit launches of a
+ * frame walk as the uncounted kernels do (forwarded bound, nearest child first, second attempts included), so the events
+ * are what the timed kernels execute — the numerator of bench.py's roofline.  Counted kernels are slower. */
+int32_t ptx_set_counting(PtxContext* ctx, int32_t enabled);
 int32_t ptx_reset_counters(PtxContext* ctx);
 int32_t ptx_get_counters(PtxContext* ctx, PtxCounters* out);
 
@@ -432,7 +436,11 @@ typedef struct PtxDebugStats {
     /* rays the nearest-first closest-hit kernels traced a second time, in reference order, because their result could
      * depend on the walk order (DESIGN.md "Nearest first"); fast_order: 1 = those kernels are in use for this scene */
     uint64_t fast_redo_rays;
-    uint32_t fast_order, _pad2;
+    uint32_t fast_order;
+    /* meshes of the uploaded scene whose triangles fail the shape certificate behind the two shortcuts (a triangle whose
+     * edges at v0 meet under less than ~0.11 degrees: Moeller-Trumbore's t is then mostly rounding); every ray whose
+     * line meets such a mesh's instance box is walked exactly as the reference walks it (DESIGN.md "Shape certificate") */
+    uint32_t uncertified_meshes;
 } PtxDebugStats;
 int32_t ptx_get_debug_stats(PtxContext* ctx, PtxDebugStats* out);
 

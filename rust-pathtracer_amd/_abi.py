@@ -156,7 +156,7 @@ class PtxDebugStats(C.Structure):
                 ("lds_stack_entries", c_u32), ("packet_lds_entries", c_u32), ("packet_capacity", c_u32),
                 ("max_leaf_undershoot", C.c_float), ("bound_forwarding", c_u32), ("max_leaf_undershoot_excess", C.c_float),
                 ("vote_closest", C.c_uint64 * 9), ("vote_any", C.c_uint64 * 9), ("stack_ops", C.c_uint64 * 4),
-                ("fast_redo_rays", C.c_uint64), ("fast_order", c_u32), ("_pad2", c_u32)]
+                ("fast_redo_rays", C.c_uint64), ("fast_order", c_u32), ("uncertified_meshes", c_u32)]
 
 
 class PtxTimings(C.Structure):

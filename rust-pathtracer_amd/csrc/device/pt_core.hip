@@ -207,7 +207,7 @@ struct BatchSink {
         else if (!found) hit(i, PTX_MISS, PTX_MISS, PT_INF, 0.0f, 0.0f);
     }
 };
-template <bool ANY, bool CNT, bool FAST = false>
+template <bool ANY, bool CNT, bool FAST = false, bool UNC = false>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits,
                                                              uint8_t* out_any, uint32_t* work, uint2* ovf, DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_batch(Scene
     uint32_t nrays = 0;
     BatchSrc src{rays};
     BatchSink<ANY> sink{out_hits, out_any};
-    trace_queue<ANY, CNT, FAST>(S, st, work, n, src, sink, lc, nrays, err, reinterpret_cast<unsigned long long*>(&dc->dbg[6]));
+    trace_queue<ANY, CNT, FAST, UNC>(S, st, work, n, src, sink, lc, nrays, err, reinterpret_cast<unsigned long long*>(&dc->dbg[6]));
     if (CNT) flush_lane_cnt(dc, lc, nrays, ANY);
 }
 
@@ -285,7 +285,8 @@ struct ExtendSink {
     }
 };
 // FAST: nearest child first + the order-independence check (pt_traverse.h); a ray that fails the check is traced again, in reference order, by its lane
-template <bool CNT, bool FAST = false>
+// UNC: the scene holds meshes that failed the shape certificate (the FAST walk then looks for their flags in the TLAS)
+template <bool CNT, bool FAST = false, bool UNC = false>
 __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S, PathArrays P, const uint32_t* q, const uint32_t* q_walk, IterCtr* ctr, uint2* ovf,
                                                         DevCounters* dc, uint32_t* err) {
     const StackRef st = make_stack(ovf);
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S
     const uint32_t n_active = ctr->n_active, n_walk = ctr->n_walk;
     ExtendSrc src{P, q, n_active, q_walk};
     ExtendSink sink{P};
-    trace_queue<false, CNT, FAST>(S, st, ctr->w_extend, n_active + n_walk, src, sink, lc, nrays, err, reinterpret_cast<unsigned long long*>(&dc->dbg[6]));
+    trace_queue<false, CNT, FAST, UNC>(S, st, ctr->w_extend, n_active + n_walk, src, sink, lc, nrays, err, reinterpret_cast<unsigned long long*>(&dc->dbg[6]));
     if (CNT) flush_lane_cnt(dc, lc, nrays, false);
 }
 
@@ -1252,6 +1253,7 @@ struct PtxContext {
     std::string err;
 
     bool has_scene = false, has_camera = false;
+    uint32_t n_uncertified = 0;     // meshes of the scene that failed the shape certificate (mesh_shapes_certified)
     SceneDev S{};
     std::vector<void*> scene_allocs;
     CameraDev cam{};
@@ -1291,6 +1293,7 @@ struct PtxContext {
     uint32_t adaptive_batch = 32;   // adaptive passes traced together by ptx_fb_adaptive_passes (PTX_ADAPTIVE_BATCH)
     bool adaptive_batch_auto = true;   // no PTX_ADAPTIVE_BATCH: start at 32 and double (up to 256) while >= 90 % of a batch's speculative samples were kept
     bool counting = false, profiling = false;
+    bool count_shipped = false;     // ptx_set_counting(ctx, 2): the counted closest-hit launches of a frame walk as the timed ones do (forwarded bound, nearest first)
     struct Ev { hipEvent_t a, b; int cls; hipStream_t stream; };
     std::vector<Ev> events;
     PtxTimings timings{};
@@ -1541,6 +1544,57 @@ static bool mesh_boxes_hold_geometry(const PtxMesh& m) {
     return true;
 }
 
+// Shape certificate.  intersect_triangle (shape/triangle_mesh.rs:63-100) divides by a = e1 . (d x e2) = |d| |e1| |e2|
+// sin(phi) cos(theta) (phi = the angle between the two edges at v0, theta = between the ray and the normal); its t, u, v
+// carry a relative rounding error of about eps / (sin(phi) |cos(theta)|).  The forwarded bound tolerates 3 %, the
+// nearest-first walk 0.4 % (pt_traverse.h) before a computed hit can sit in front of a box that walk has culled while
+// the reference's walk still visits it.  Measured (tests/probe_adversarial.py, 2 M random + 320 k aimed rays per scene
+// against clouds of needle triangles with well-shaped walls among them): random rays never differ from the reference,
+// whatever the aspect (up to 10^6); rays AIMED at a triangle hidden behind a nearer surface, within an angle theta_c of
+// its plane, do: theta_c ~ 10^-6 rad for aspect 1-4, 10^-5 for 10-110, 10^-3 for 300-1000, any angle from 10^4 on.
+// The certificate draws the line at sin(phi) >= 2^-9 (aspect ~500, phi ~0.11 degrees): a mesh with a sharper triangle is
+// walked as the reference walks it, by every ray that could reach it (the procedural scenes' sharpest: 0.29 degrees).
+// What stays presumed for certified meshes is the statement above for aimed rays within ~10^-3 rad; PTX_EXACT_ORDER=1
+// PTX_NO_FORWARD=1 drops both shortcuts for anyone who needs the reference's garbage hits as well.
+// Edges of length zero are fine: a is then exactly 0 and the triangle is always rejected (|a| < 1e-8).
+constexpr double SHAPE_MIN_SIN = 1.0 / 512.0;
+static bool mesh_shapes_certified(const PtxMesh& m) {
+    for (uint32_t t = 0; t < m.n_triangles; ++t) {
+        const uint32_t* tri = &m.indices[3 * (size_t)t];
+        const float* p0 = &m.positions[3 * (size_t)tri[0]]; const float* p1 = &m.positions[3 * (size_t)tri[1]]; const float* p2 = &m.positions[3 * (size_t)tri[2]];
+        // the f32 edges the kernels use (TriRec)
+        const double e1[3] = {(double)(p1[0] - p0[0]), (double)(p1[1] - p0[1]), (double)(p1[2] - p0[2])};
+        const double e2[3] = {(double)(p2[0] - p0[0]), (double)(p2[1] - p0[1]), (double)(p2[2] - p0[2])};
+        const double n1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), n2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+        if (n1 == 0.0 || n2 == 0.0) continue;
+        const double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double area2 = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        if (!(area2 >= SHAPE_MIN_SIN * n1 * n2)) return false;      // also NaN / inf coordinates
+    }
+    return true;
+}
+
+// META_UNCERT on every TLAS child whose subtree holds an instance of an uncertified mesh (all TLAS trees: records
+// [0, n_records) of `nodes`).  Returns whether the record itself holds one.
+static bool flag_uncertified(std::vector<NodeRec>& nodes, uint32_t word, const std::vector<uint32_t>& tlas_prims,
+                             const std::vector<uint8_t>& inst_uncert, uint32_t depth = 0) {
+    const uint32_t unit = word & NODE_INDEX_MASK, nchild = ((word >> NODE_NCHILD_SHIFT) & NODE_NCHILD_MASK) + 1u;
+    bool any = false;
+    if (depth > REPACK_MAX_DEPTH + 8) return false;
+    for (uint32_t k = 0; k < nchild; ++k) {
+        float4& hi = nodes[unit + k / 4].c[2 * (k % 4) + 1];
+        uint32_t cw, meta;
+        std::memcpy(&cw, &hi.z, 4); std::memcpy(&meta, &hi.w, 4);
+        bool f = false;
+        if (cw & LEAF_FLAG) {
+            const uint32_t start = cw & PRIM_START_MASK, cnt = ((cw >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
+            for (uint32_t j = start; j < start + cnt && j < tlas_prims.size(); ++j) f = f || inst_uncert[tlas_prims[j]] != 0;
+        } else f = flag_uncertified(nodes, cw, tlas_prims, inst_uncert, depth + 1);
+        if (f) { meta |= META_UNCERT; std::memcpy(&hi.w, &meta, 4); any = true; }
+    }
+    return any;
+}
+
 static void pack_cols(const float* m, float4* dst) {
     // columns x,y,z,w (xyz of each) -> 3 float4
     dst[0] = make_float4(m[0], m[1], m[2], m[4]);
@@ -1718,6 +1772,12 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
     bool drained = false;
     const bool side = ctx->overlap_shadow && !ctx->counting && ctx->side_stream != nullptr;
     bool side_pending = false;      // work on the side stream the main stream has not been ordered behind yet
+    // An early return below (a failed HIP call, the subsurface poll, a packet launch) must not leave side-stream kernels
+    // running behind the caller's next main-stream call: they still write P and the framebuffer.
+    struct SideJoin {
+        PtxContext* c; bool armed = false;
+        ~SideJoin() { if (armed && c->side_stream) (void)hipStreamSynchronize(c->side_stream); }
+    } side_join{ctx};
     for (uint32_t it = 0; it < iter_cap; ++it) {
         uint32_t* qa = ctx->q[it & 1];
         uint32_t* qb = ctx->q[(it + 1) & 1];
@@ -1733,10 +1793,16 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
             } else {
                 const bool fast = ctx->S.fast_on != 0u && !ctx->counting;
                 ScopedEvent ev(ctx, CLS_EXTEND);
-                if (ctx->counting && ctx->S.fwd_on == 2u && ctx->S.fast_on)      // PTX_COUNT_FORWARD=1 (measurement only): count what the shipped walk does
-                    hipLaunchKernelGGL((k_extend<true, true>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                if (ctx->counting && (ctx->S.fwd_on == 2u || (ctx->count_shipped && ctx->S.fwd_on)) && ctx->S.fast_on) {
+                    // ptx_set_counting(ctx, 2) / PTX_COUNT_FORWARD=1: count what the shipped per-ray walk does (its node visits,
+                    // triangle tests and entries, second attempts included) instead of what the reference's walk does
+                    SceneDev Sc = ctx->S;
+                    Sc.fwd_on = 2u;
+                    hipLaunchKernelGGL((k_extend<true, true, true>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, Sc, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                }
                 else if (ctx->counting) hipLaunchKernelGGL((k_extend<true, false>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
-                else if (fast) hipLaunchKernelGGL((k_extend<false, true>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                else if (fast && ctx->n_uncertified) hipLaunchKernelGGL((k_extend<false, true, true>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
+                else if (fast) hipLaunchKernelGGL((k_extend<false, true, false>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
                 else hipLaunchKernelGGL((k_extend<false, false>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
             }
         }
@@ -1762,6 +1828,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
         hipStream_t ss = side ? ctx->side_stream : ctx->stream;
         uint2* sovf = side ? ctx->ovf_side : ctx->ovf;
         if (side) {
+            side_join.armed = true;
             HIPCHK(hipEventRecord(ctx->ev_main, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ss, ctx->ev_main, 0));
         }
@@ -1790,6 +1857,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
     }
     // whatever follows on the main stream (accumulation, readbacks, the next batch's k_raygen) comes after the side stream's work
     if (side_pending) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+    side_join.armed = false;        // joined through the event: no host wait on the normal road
     HIPCHK(hipGetLastError());
     // Without SSS every path ends by iteration max_bounces (k_shade retires it at bounce >= max_bounces).  With SSS a
     // path that is still walking after MAX_ITERS - 1 iterations would never reach k_finalize: refuse instead of
@@ -1922,6 +1990,9 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
     }
     const uint32_t n_tlas_records = (uint32_t)nodes.size();
     bool forward_ok = true;      // forwarded_bound needs triangles inside the boxes above them, in every mesh
+    std::vector<uint8_t> mesh_uncert(sc->n_meshes, 0);      // meshes that fail the shape certificate
+    const char* no_cert = std::getenv("PTX_NO_SHAPE_CERT");     // measurement only: what the shortcuts do to ill-shaped meshes without it
+    const bool shape_cert = !(no_cert && no_cert[0] == '1');
     for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
         const PtxMesh& m = sc->meshes[mi];
         if (!m.positions || !m.indices || !m.n_triangles) return fail(ctx, PTX_ERR_INVALID, "mesh without geometry");
@@ -1948,6 +2019,7 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
         for (uint32_t s = 0; s < m.bvh.n_primitive_indices; ++s)
             if (m.bvh.primitive_indices[s] >= m.n_triangles) return fail(ctx, PTX_ERR_INVALID, "mesh BVH primitive index out of range");
         if (!nests || !mesh_boxes_hold_geometry(m)) forward_ok = false;
+        mesh_uncert[mi] = (shape_cert && !mesh_shapes_certified(m)) ? 1 : 0;
         for (uint32_t s = 0; s < m.bvh.n_primitive_indices; ++s) {
             const uint32_t t = m.bvh.primitive_indices[s];
             const uint32_t* tri = &m.indices[3 * (size_t)t];
@@ -1974,7 +2046,7 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
         pack_cols(in.inverse_transform, &r.m[0]);
         r.m[3] = make_float4(m.bounds_min[0], m.bounds_min[1], m.bounds_min[2], m.bounds_max[0]);
         float nb, tb;
-        const uint32_t nb_word = mesh_root_word_ray[in.blas_index];
+        const uint32_t nb_word = mesh_root_word_ray[in.blas_index] | (mesh_uncert[in.blas_index] ? INST_UNCERT : 0u);
         std::memcpy(&nb, &nb_word, 4);
         std::memcpy(&tb, &meshes[in.blas_index].tri_base, 4);
         r.m[4] = make_float4(m.bounds_max[1], m.bounds_max[2], nb, tb);
@@ -2016,6 +2088,13 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
     std::vector<float> bn_pixel(sc->blue_noise_pixel.samples, sc->blue_noise_pixel.samples + bn);
     std::vector<float> bn_lens(sc->blue_noise_lens.samples, sc->blue_noise_lens.samples + bn);
 
+    ctx->n_uncertified = 0;
+    for (uint8_t f : mesh_uncert) ctx->n_uncertified += f;
+    if (ctx->n_uncertified && sc->n_instances) {
+        std::vector<uint8_t> inst_uncert(sc->n_instances);
+        for (uint32_t i = 0; i < sc->n_instances; ++i) inst_uncert[i] = mesh_uncert[sc->instances[i].blas_index];
+        for (uint32_t root : {tlas_root_word, tlas_root_word_ray, tlas_root_word_packet}) flag_uncertified(nodes, root, tlas_prims, inst_uncert);
+    }
     auto& pool = ctx->scene_allocs;
     HIPCHK(dev_upload(pool, &S.nodes, nodes)); HIPCHK(dev_upload(pool, &S.tlas_prims, tlas_prims)); HIPCHK(dev_upload(pool, &S.tris, tris));
     std::vector<InstRec> inst_tlas(tlas_prims.size());
@@ -2147,8 +2226,7 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
             const char* exact_order = std::getenv("PTX_EXACT_ORDER");
             S.fast_on = (S.fwd_on != 0u && omax < 1e30 && slack < 1e30 && !(exact_order && exact_order[0] == '1')) ? 1u : 0u;
             S.fast_omax = (float)omax; S.fast_slack = (float)slack;
-            S.fast_cull = FAST_CULL; S.fast_band = FAST_BAND;
-            if (std::getenv("PTX_VERBOSE")) fprintf(stderr, "[ptx] forwarding %u (lin %.3g, tr %.3g); nearest-first %u (|o|_1 <= %.4g, slack %.3g)\n", S.fwd_on, lin, tr, S.fast_on, omax, slack);
+            if (std::getenv("PTX_VERBOSE")) fprintf(stderr, "[ptx] forwarding %u (lin %.3g, tr %.3g); nearest-first %u (|o|_1 <= %.4g, slack %.3g); %u of %u meshes fail the shape certificate\n", S.fwd_on, lin, tr, S.fast_on, omax, slack, ctx->n_uncertified, sc->n_meshes);
         }
     }
     // shading triangles: built on the device from the pools just uploaded, one launch per mesh
@@ -2605,7 +2683,8 @@ int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t
             hipLaunchKernelGGL(k_trace_batch_packet<false>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_err, ctx->d_counters);
         } else {
             if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
-            else if (ctx->S.fast_on) hipLaunchKernelGGL((k_trace_batch<false, false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
+            else if (ctx->S.fast_on && ctx->n_uncertified) hipLaunchKernelGGL((k_trace_batch<false, false, true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
+            else if (ctx->S.fast_on) hipLaunchKernelGGL((k_trace_batch<false, false, true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
         }
         delete ev;
@@ -2638,7 +2717,8 @@ int32_t ptx_trace_batch_noalloc(PtxContext* ctx, const PtxRay* d_rays, uint64_t 
         else hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, d_out_any, d_work, d_ovf, ctx->d_counters, d_err);
     } else {
         if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, d_out_hits, (uint8_t*)nullptr, d_work, d_ovf, ctx->d_counters, d_err);
-        else if (ctx->S.fast_on) hipLaunchKernelGGL((k_trace_batch<false, false, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, d_out_hits, (uint8_t*)nullptr, d_work, d_ovf, ctx->d_counters, d_err);
+        else if (ctx->S.fast_on && ctx->n_uncertified) hipLaunchKernelGGL((k_trace_batch<false, false, true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, d_out_hits, (uint8_t*)nullptr, d_work, d_ovf, ctx->d_counters, d_err);
+        else if (ctx->S.fast_on) hipLaunchKernelGGL((k_trace_batch<false, false, true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, d_out_hits, (uint8_t*)nullptr, d_work, d_ovf, ctx->d_counters, d_err);
         else hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, d_out_hits, (uint8_t*)nullptr, d_work, d_ovf, ctx->d_counters, d_err);
     }
     HIPCHK(hipGetLastError());
@@ -2683,7 +2763,7 @@ int32_t ptx_debug_math(PtxContext* ctx, int32_t fn, const float* x, const float*
     return st;
 }
 
-int32_t ptx_set_counting(PtxContext* ctx, int32_t enabled) { REQUIRE_CTX(); ctx->counting = enabled != 0; return PTX_OK; }
+int32_t ptx_set_counting(PtxContext* ctx, int32_t enabled) { REQUIRE_CTX(); ctx->counting = enabled != 0; ctx->count_shipped = enabled == 2; return PTX_OK; }
 int32_t ptx_reset_counters(PtxContext* ctx) {
     REQUIRE_CTX();
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(DevCounters), ctx->stream));
@@ -2705,7 +2785,7 @@ int32_t ptx_get_debug_stats(PtxContext* ctx, PtxDebugStats* out) {
     HIPCHK(hipMemcpy(dbg, ctx->d_counters->dbg, sizeof(dbg), hipMemcpyDeviceToHost));
     out->fast_redo_rays = (uint64_t)dbg[6] | ((uint64_t)dbg[7] << 32);
     out->fast_order = ctx->has_scene ? ctx->S.fast_on : 0u;
-    out->_pad2 = 0;
+    out->uncertified_meshes = ctx->has_scene ? ctx->n_uncertified : 0u;
     std::memcpy(&out->max_leaf_undershoot, &dbg[4], 4);
     HIPCHK(hipMemcpy(out->vote_closest, ctx->d_counters->vote, sizeof(uint64_t) * 18, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out->stack_ops, ctx->d_counters->stk, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));

@@ -161,6 +161,18 @@ PT_DEV uint2 st_read(const StackRef& s, int i) {
     return v;
 }
 
+// the distance half of an entry alone (do_tri's check of a hit against its leaf's entry distance)
+PT_DEV float st_read_dist(const StackRef& s, int i) {
+    uint32_t v;
+    if (i < LDS_STACK) {
+        v = s_stack[i * TRACE_BLOCK + (int)threadIdx.x].y;
+        asm volatile("" : "+v"(v));
+    } else {
+        v = s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride + strip_lane()].y;
+    }
+    return __uint_as_float(v);
+}
+
 // stack_hw: deepest stack this lane reached; undershoot: largest (t_enter(leaf box) - t) / t over the triangle hits this
 // lane computed (how far a hit can lie in front of the boxes above it: forwarded_bound tolerates 2^-5) — counted kernels
 // vote[0] = loop iterations of this wave, vote[1..4] = iterations in which the NODE / TRI / ENTER / EXIT action ran,
@@ -234,14 +246,23 @@ PT_DEV float forwarded_bound(const SceneDev& S, V3 o, V3 d, float ct) {
 // around it by more than a factor 1 + 2^-10 plus the certified rounding slack).  A ray that ends with the flag set, a
 // NaN-slab ray, a ray outside the certified range of the slack (origin far outside the scene, direction far from unit
 // length) is traced again by the same lane in reference order (`slow`): same kernel, no second launch.
-constexpr float FAST_CULL = 1.00390625f;     // 1 + 2^-8
-constexpr float FAST_BAND = 1.001953125f;    // 1 + 2^-9
+constexpr float FAST_CULL = 1.00390625f;     // 1 + 4m, m = 2^-10
+constexpr float FAST_BAND = 1.001953125f;    // 1 + 2m
+constexpr float FAST_UNDER = 1.0009765625f;  // 1 + m: the undershoot every hit a nearest-first lane accepts is checked against (do_tri)
+// The absolute parts: the band carries `slack` once, the cull four times (three are needed; four is the multiple an
+// instance entry already keeps in a register, a fifth constant spills).  A hit Z in a box culled at
+// entry >= t(Y) (1 + 4m) + 4 slack has, under the presumption entry <= t(Z) (1 + m) + slack,
+// t(Z) (1 + m) >= t(Y) (1 + 4m) + 3 slack, i.e. t(Z) > t(Y) (1 + 2m) + slack for every t(Y) >= 0 — beyond the band also at
+// short range, where slack > m t(Y) (with the same absolute term on both sides the slack cancelled and the margin shrank
+// to ~3m t(Y): ADVICE r2).
+constexpr float FAST_CULL_SLACKS = 4.0f;
 
 enum : uint32_t { ACT_IDLE = 0, ACT_NODE = 1, ACT_TRI = 2, ACT_ENTER = 3, ACT_EXIT = 4, ACT_POP = 5, ACT_DONE = 6 };
 
 // Per-lane traversal state.  The world ray is not kept while a lane is inside an instance: it is re-read from the
 // queue entry when the instance is left; the closest hit is written through the sink when it is accepted.
-template <bool ANY, bool CNT, bool FAST = false>
+// UNC (FAST kernels): the scene holds meshes that failed the shape certificate; the TLAS visit looks for their flags
+template <bool ANY, bool CNT, bool FAST = false, bool UNC = false>
 struct Traverser {
     V3 o, d, inv;              // ray of the level being traversed
     float ct;                  // closest_t of that level (ANY: its ray.t_max)
@@ -282,8 +303,8 @@ struct Traverser {
         }
     }
     // FAST: what an entry distance is compared with (pop-time cull, the box test's t_max)
-    PT_DEV float cull_bound(const SceneDev& S) const { return fast() ? ct * S.fast_cull + S.fast_slack : ct; }
-    PT_DEV float band_bound(const SceneDev& S, float best) const { return best * S.fast_band + S.fast_slack; }
+    PT_DEV float cull_bound(const SceneDev& S) const { return fast() ? ct * FAST_CULL + FAST_CULL_SLACKS * S.fast_slack : ct; }
+    PT_DEV float band_bound(const SceneDev& S, float best) const { return best * FAST_BAND + S.fast_slack; }
 
     // ---- pop entries until one needs work; sets the next action (accel/bvh.rs:322-329) ---------------
     PT_DEV void pop(const SceneDev& S, const StackRef& st, LaneCnt& lc) {
@@ -349,9 +370,9 @@ struct Traverser {
                 const float xa3 = s3 ? kb : ka, xb3 = s3 ? ka : kb; const uint32_t ya3 = s3 ? wb : wa, yb3 = s3 ? wa : wb;
                 ka = xa3; kb = xb3; wa = ya3; wb = yb3;
             }
-            if (ka >= 0.0f) { st_write(st, sp, wa, __float_as_uint(ka)); ++sp; }
-            if (kb >= 0.0f) { st_write(st, sp, wb, __float_as_uint(kb)); ++sp; }
-            if (kc >= 0.0f) { st_write(st, sp, wc, __float_as_uint(kc)); ++sp; }
+            if (ka >= 0.0f) { if (CNT) { lcp->stk_writes++; if (sp >= LDS_STACK) lcp->stk_writes_hbm++; } st_write(st, sp, wa, __float_as_uint(ka)); ++sp; }
+            if (kb >= 0.0f) { if (CNT) { lcp->stk_writes++; if (sp >= LDS_STACK) lcp->stk_writes_hbm++; } st_write(st, sp, wb, __float_as_uint(kb)); ++sp; }
+            if (kc >= 0.0f) { if (CNT) { lcp->stk_writes++; if (sp >= LDS_STACK) lcp->stk_writes_hbm++; } st_write(st, sp, wc, __float_as_uint(kc)); ++sp; }
             return;
         }
         if (WIDE && nb > 3u) { const float4 d0 = q[6], d1 = q[7]; visit_child<EXACT>(st, d0, d1, true, tmax); }
@@ -371,6 +392,30 @@ struct Traverser {
         // 64 per level and panic beyond (accel/bvh.rs:320,361,379,408)
         if (sp + (int)nchild > STACK_CAP) { atomicOr(err, 1u); found = false; act = ACT_DONE; return; }
         act = ACT_POP;
+        if (FAST && UNC && !ANY) {      // compiled in only for scenes that hold an uncertified mesh (k_extend<.., true, true>)
+            // A nearest-first lane culls by distance what the reference's walk may still visit.  That is only sound for
+            // meshes that passed the shape certificate: a lane whose ray meets the box of a TLAS child holding an
+            // uncertified instance AT ANY DISTANCE (the reference's closest_t at that point is unknown, so none is
+            // assumed) starts over in reference order.  Mesh records carry no such flag; scenes without an uncertified
+            // mesh run the instantiation without this block.
+            uint32_t fl = (__float_as_uint(r1.w) | __float_as_uint(r3.w) | __float_as_uint(r5.w)) & META_UNCERT;
+            if (WIDE) fl |= META_UNCERT & (nchild > 3u ? 0xFFFFFFFFu : 0u);      // records of 4..8 children (host trees): look at every child
+            if (fl != 0u && fast() && !in_mesh) {
+                bool touch = false;
+                float te;
+                if (!WIDE) {      // <= 3 children, already in registers
+                    touch = ((__float_as_uint(r1.w) & META_UNCERT) != 0u && box_test<true>(r0, r1, o, inv, RAY_EPSILON, PT_INF, &te)) ||
+                            ((__float_as_uint(r3.w) & META_UNCERT) != 0u && box_test<true>(r2, r3, o, inv, RAY_EPSILON, PT_INF, &te)) ||
+                            ((__float_as_uint(r5.w) & META_UNCERT) != 0u && box_test<true>(r4, r5, o, inv, RAY_EPSILON, PT_INF, &te));
+                } else {
+                    for (uint32_t k = 0; k < nchild; ++k) {
+                        const float4 lo = p[2u * k], hi = p[2u * k + 1u];
+                        if ((__float_as_uint(hi.w) & META_UNCERT) != 0u && box_test<true>(lo, hi, o, inv, RAY_EPSILON, PT_INF, &te)) touch = true;
+                    }
+                }
+                if (touch) { amb_w = true; found = false; act = ACT_DONE; return; }
+            }
+        }
         if (WIDE && nchild > 4u) {
             // a record of two units: its children 7..4 now (they are pushed first), its children 3..0 in the lane's next
             // node action — the lane stays in ACT_NODE with the record's first unit as a 4-child record.  Two short
@@ -387,7 +432,7 @@ struct Traverser {
     }
 
     // ---- ACT_TRI: intersect_triangle on the next primitive of the leaf ------------------
-    PT_DEV void do_tri(const SceneDev& S, LaneCnt& lc, const float4 ta, const float4 tb, const float4 tc) {
+    PT_DEV void do_tri(const SceneDev& S, const StackRef& st, LaneCnt& lc, const float4 ta, const float4 tb, const float4 tc) {
         const float tmin = RAY_EPSILON;
         if (CNT) { lc.prim_reads++; lc.tri_tests++; }
         pw += 1u; tri_cnt -= 1u;
@@ -414,6 +459,16 @@ struct Traverser {
             }
             if (ANY) { found = true; act = ACT_DONE; return; }
             if (FAST) {
+                // The presumption the margins rest on, checked on every hit a nearest-first lane is about to accept: the
+                // hit does not lie in front of its leaf box's entry distance by more than (1 + m) and the slack.  The
+                // leaf's stack entry still sits in the slot it was popped from (a triangle action pushes nothing), so
+                // this costs one stack read per HIT, no register.  A hit that fails (a sliver triangle met at a grazing
+                // angle: Moeller-Trumbore's t is then mostly rounding) sends the ray to the reference order.
+                if (fast() && t < ct) {
+                    // (read here, inside the hit branch: hoisted above the arithmetic the read costs 9 ms per frame)
+                    const float ld = st_read_dist(st, sp);
+                    if (ld > t * FAST_UNDER + S.fast_slack) { amb_w = true; found = false; act = ACT_DONE; return; }
+                }
                 // a second hit within the band of the instance's best one: which of them the reference's walk returns depends on its order
                 const bool have = m_tri != PTX_MISS;
                 if (t < ct) amb_l = have && ct <= band_bound(S, t);
@@ -444,11 +499,13 @@ struct Traverser {
         bool bhit;
         if (__ballot(lexact) != 0ull) bhit = box_test<true>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
         else bhit = box_test<false>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
-        if (fast() && lexact) { amb_w = true; found = false; act = ACT_DONE; return; }      // NaN slabs in the local frame: start over in reference order
+        // an instance of a mesh that failed the shape certificate (pt_types.h): the reference's walk, operation for operation
+        const bool uncert = (__float_as_uint(b1.z) & INST_UNCERT) != 0u;
+        if (fast() && (lexact || uncert)) { amb_w = true; found = false; act = ACT_DONE; return; }      // NaN slabs in the local frame / uncertified: start over in reference order
         if (FAST) amb_l = false;
         // a nearest-first lane must SEE every local hit that could tie with the best one: its bound carries the scene-wide
         // slack (>= this ray's rounding bound) four times over instead of the per-ray term
-        const float bound = (ANY || exact || lexact || (CNT && S.fwd_on < 2u)) ? PT_INF
+        const float bound = (ANY || exact || lexact || uncert || (CNT && S.fwd_on < 2u)) ? PT_INF
                             : fast() ? ct * 1.03125f + 4.0f * S.fast_slack : forwarded_bound(S, o, d, ct);
         if (!bhit || (!ANY && tb_enter >= bound)) { act = ACT_POP; return; }
         if (CNT) lc.prim_reads++;   // the Blas leaf's own primitive index
@@ -465,7 +522,7 @@ struct Traverser {
         tri_base = __float_as_uint(b1.w);
         m_tri = PTX_MISS;
         // root record of the mesh BVH (absolute), child count in the top bits: wide tree, or the faithful one
-        pw = faithful() ? S.inst_root_faithful[start] : __float_as_uint(b1.z);
+        pw = faithful() ? S.inst_root_faithful[start] : (__float_as_uint(b1.z) & ~INST_UNCERT);
         act = ACT_NODE;
     }
 
@@ -490,7 +547,10 @@ struct Traverser {
                 // this instance's winner against the best so far; a winner that is itself in doubt (amb_l) stands for
                 // hits down to one band below it
                 if (amb_l && t_world <= band_bound(S, band_bound(S, ct_world))) amb_w = true;
-                if (t_world < ct_world) { if (!amb_l) amb_w = found && ct_world <= band_bound(S, t_world); }
+                // (the ray's own finite t_max stands for a hit as well: the reference skips an instance whose box is
+                // entered at or beyond it, accel/bvh.rs:327,345, where this walk would still enter and accept — ADVICE r2)
+                const bool rival = found || ct_world < PT_INF;
+                if (t_world < ct_world) { if (!amb_l) amb_w = rival && ct_world <= band_bound(S, t_world); }
                 else if (found && t_world <= band_bound(S, ct_world)) amb_w = true;
             }
             if (t_world < ct_world) {                               // traverse_closest accept (accel/bvh.rs:353-357)
@@ -514,14 +574,14 @@ struct Traverser {
 // call for an entry is its result); `Sink::done(k, found)` ends the entry.
 // `work` is the queue's shared cursor, `n` its length.
 // FAST (closest-hit only): see above.
-template <bool ANY, bool CNT, bool FAST = false, class Src, class Sink>
+template <bool ANY, bool CNT, bool FAST = false, bool UNC = false, class Src, class Sink>
 PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink,
                         LaneCnt& lc, uint32_t& nrays, uint32_t* err,       // err: the device error word (set on a stack overflow)
                         unsigned long long* again_count = nullptr) {            // FAST: statistics, rays traced a second time
     // a short queue cannot feed every wave: the surplus ones leave without touching the cursors (6144 waves bumping
     // a few addresses made an empty launch cost 70 us)
     if ((unsigned long long)blockIdx.x * 16ull >= (unsigned long long)n + 128ull) return;
-    Traverser<ANY, CNT, FAST> tv;
+    Traverser<ANY, CNT, FAST, UNC> tv;
     tv.act = ACT_IDLE;
     tv.exact = false; tv.in_mesh = false; tv.found = false; tv.amb_w = false; tv.amb_l = false; tv.slow = false;
     uint32_t n_again = 0;
@@ -623,7 +683,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
             r0 = p[0]; r1 = p[1]; r2 = p[2];
             if (f_node) { r3 = p[3]; r4 = p[4]; r5 = p[5]; }
         }
-        if (f_tri) tv.do_tri(S, lc, r0, r1, r2);
+        if (f_tri) tv.do_tri(S, st, lc, r0, r1, r2);
         if (f_node) {
             if (wave_exact) tv.template do_node<true, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
             else if (wave_wide) tv.template do_node<false, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
@@ -830,7 +890,8 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                     bool bhit;
                     if (__ballot(act && lexact) != 0ull) bhit = box_test<true>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
                     else bhit = box_test<false>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
-                    const float bound = (ANY || exact || lexact) ? PT_INF : forwarded_bound(S, o, d, ct);
+                    const bool uncert = (__float_as_uint(b1.z) & INST_UNCERT) != 0u;      // wave-uniform: shape certificate failed, no forwarding
+                    const float bound = (ANY || exact || lexact || uncert) ? PT_INF : forwarded_bound(S, o, d, ct);
                     const bool enter = act && bhit && (ANY || !(tb_enter >= bound));
                     const unsigned long long em = __ballot(enter);
                     if (em == 0ull) continue;

@@ -38,6 +38,13 @@ struct NodeRec { float4 c[8]; };
 static_assert(sizeof(NodeRec) == 128, "node record unit must be one 128-byte line");
 
 constexpr uint32_t LEAF_FLAG = 0x80000000u;
+// Shape certificate (upload): a mesh with a triangle whose edges at v0 are nearly parallel is UNCERTIFIED — the shortcuts
+// of the closest-hit kernels (forwarded bound, nearest-first order) presume triangle hits that sit inside the boxes above
+// them, which such triangles break.  Marked in two places: bit 31 of the per-ray root word in the instance record
+// (InstRec::m[4].z; a mesh root is never a leaf word), and META_UNCERT in the meta word of every TLAS child whose subtree
+// holds an instance of such a mesh (children 1.. of a record use their meta word for nothing else).
+constexpr uint32_t INST_UNCERT = 0x80000000u;
+constexpr uint32_t META_UNCERT = 1u << 8;
 constexpr uint32_t NODE_NCHILD_SHIFT = 28;
 constexpr uint32_t NODE_NCHILD_MASK = 7u;
 constexpr uint32_t NODE_INDEX_MASK = (1u << NODE_NCHILD_SHIFT) - 1u;
@@ -141,7 +148,7 @@ struct SceneDev {
     // FAST traversal (pt_traverse.h): rays whose origin has |o|_1 <= fast_omax (the scene's extent) may take it;
     // fast_slack = the world/local rounding bound at that extent, the absolute part of every FAST margin
     uint32_t fast_on;
-    float fast_omax, fast_slack, fast_cull, fast_band;     // cull factor 1 + 4m, band factor 1 + 2m
+    float fast_omax, fast_slack;                           // (the relative margins are compile-time constants: pt_traverse.h FAST_*)
 };
 
 struct CameraDev {

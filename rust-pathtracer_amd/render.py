@@ -274,7 +274,8 @@ class HipRenderLoop:
 
     # -- measurement -----------------------------------------------------------------
     def set_counting(self, on):
-        self._check(self.L.ptx_set_counting(self._h, 1 if on else 0), "ptx_set_counting")
+        """False / 0 off; True / 1 the reference's events; 2 the shipped walk's events (include/ptx_core.h)."""
+        self._check(self.L.ptx_set_counting(self._h, int(on)), "ptx_set_counting")
 
     def reset_counters(self):
         self._check(self.L.ptx_reset_counters(self._h), "ptx_reset_counters")
