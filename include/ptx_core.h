@@ -356,6 +356,14 @@ int32_t ptx_fb_export_dev(PtxContext* ctx, float* d_sum, float* d_sum_sq, uint32
 uint64_t ptx_fb_tiles_bytes(uint32_t width, uint32_t height, uint32_t world);
 int32_t ptx_fb_export_tiles_dev(PtxContext* ctx, void* d_out, uint64_t capacity_bytes);
 int32_t ptx_fb_import_tiles_dev(PtxContext* ctx, const void* d_in, uint32_t src_rank, uint32_t world);
+/* Ordering between the library's own stream and a caller's HIP stream without stalling the host (no counterpart in the
+ * reference: one process, no streams).  `stream` is a hipStream_t (NULL = the default stream).
+ * ptx_order_after_stream: everything the library enqueues from now on runs after the work ALREADY enqueued on `stream`
+ * (e.g. a collective that wrote the buffer ptx_fb_import_tiles_dev is about to read).
+ * ptx_order_stream_after: work enqueued on `stream` from now on runs after everything the library has enqueued so far
+ * (e.g. a collective that reads the buffer ptx_fb_export_tiles_dev just filled). */
+int32_t ptx_order_after_stream(PtxContext* ctx, void* stream);
+int32_t ptx_order_stream_after(PtxContext* ctx, void* stream);
 
 /* One whole frame in one call: the `for sample` loop of `run_benchmark`
  * (src/main.rs:123-141) and, with `adaptive` non-NULL, the progressive loop of

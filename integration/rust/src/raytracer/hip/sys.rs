@@ -162,6 +162,80 @@ pub struct PtxFrameStats {
     pub adaptive_samples: u64,
 }
 
+/// Event counts behind the algorithmic bytes: filled by the counted kernels.
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct PtxCounters {
+    pub rays_closest: u64,
+    pub rays_any: u64,
+    pub node_visits: u64,
+    pub node_children: u64,
+    pub prim_index_reads: u64,
+    pub triangle_tests: u64,
+    pub instance_entries: u64,
+    pub instance_hits: u64,
+    pub hitdata_built: u64,
+    pub material_fetches: u64,
+    pub texture_lookups: u64,
+    pub cdf_probes: u64,
+    pub sky_pdf_evals: u64,
+    pub sky_texel_lookups: u64,
+    pub primary_rays: u64,
+    pub pixel_samples_written: u64,
+    pub sss_steps: u64,
+    pub any_node_visits: u64,
+    pub any_node_children: u64,
+    pub any_prim_index_reads: u64,
+    pub any_triangle_tests: u64,
+    pub any_instance_entries: u64,
+}
+
+/// Per-kernel-class device time since the last reset (HIP events on the library's streams).
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct PtxTimings {
+    pub raygen_ms: f64,
+    pub extend_ms: f64,
+    pub shade_ms: f64,
+    pub shadow_ms: f64,
+    pub accumulate_ms: f64,
+    pub other_ms: f64,
+    pub extend_launches: u64,
+    pub shade_launches: u64,
+    pub shadow_launches: u64,
+    pub packet_ms: f64,
+    pub packet_launches: u64,
+    pub walk_ms: f64,
+    pub walk_launches: u64,
+}
+
+/// Which traversal roads the launches since `ptx_reset_counters` took (stack high-water marks, packet redo, the
+/// measured undershoot the shortcuts presume, the wave vote, second attempts, uncertified meshes).
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct PtxDebugStats {
+    pub trace_stack_high_water: u32,
+    pub packet_stack_high_water: u32,
+    pub packet_redo_rays: u64,
+    pub lds_stack_entries: u32,
+    pub packet_lds_entries: u32,
+    pub packet_capacity: u32,
+    pub max_leaf_undershoot: f32,
+    pub bound_forwarding: u32,
+    pub max_leaf_undershoot_excess: f32,
+    pub vote_closest: [u64; 9],
+    pub vote_any: [u64; 9],
+    pub stack_ops: [u64; 4],
+    pub fast_redo_rays: u64,
+    pub fast_order: u32,
+    pub uncertified_meshes: u32,
+}
+
+pub const PTX_TONEMAP_NONE: i32 = 0;
+pub const PTX_TONEMAP_ACES: i32 = 1;
+pub const PTX_TONEMAP_REINHARD: i32 = 2;
+pub const PTX_TONEMAP_AGX: i32 = 3;
+
 #[link(name = "mi355_pt")]
 extern "C" {
     pub fn ptx_create(device_index: i32, out_ctx: *mut *mut PtxContext) -> i32;
@@ -193,4 +267,22 @@ extern "C" {
     pub fn ptx_fb_tiles_bytes(width: u32, height: u32, world: u32) -> u64;
     pub fn ptx_fb_export_tiles_dev(ctx: *mut PtxContext, d_out: *mut core::ffi::c_void, capacity_bytes: u64) -> i32;
     pub fn ptx_fb_import_tiles_dev(ctx: *mut PtxContext, d_in: *const core::ffi::c_void, src_rank: u32, world: u32) -> i32;
+    /// Stream ordering without a host stall: the library after `stream`'s enqueued work / `stream` after the library's.
+    pub fn ptx_order_after_stream(ctx: *mut PtxContext, stream: *mut core::ffi::c_void) -> i32;
+    pub fn ptx_order_stream_after(ctx: *mut PtxContext, stream: *mut core::ffi::c_void) -> i32;
+    /// `ToneMap::apply_with_exposure` + `linear_to_srgb_u8` on the device: w*h*3 bytes leave the GPU (exporter/tonemapping.rs:12-115).
+    pub fn ptx_fb_tonemap_srgb8(ctx: *mut PtxContext, tonemap: i32, exposure: f32, out_rgb8: *mut u8) -> i32;
+    /// The accumulators into caller-owned DEVICE memory, ordered on the library stream.
+    pub fn ptx_fb_export_dev(ctx: *mut PtxContext, d_sum: *mut f32, d_sum_sq: *mut f32, d_counts: *mut u32) -> i32;
+    /// The primary rays `render_pixel` would generate (renderloop/parallel.rs:31-56).
+    pub fn ptx_generate_primary_rays(ctx: *mut PtxContext, width: u32, height: u32, sample_index: u32, out_rays: *mut PtxRay) -> i32;
+    pub fn ptx_debug_math(ctx: *mut PtxContext, func: i32, x: *const f32, y: *const f32, n: u64, out: *mut f32) -> i32;
+    /// 0 off, 1 the reference's events, 2 the shipped walk's events.
+    pub fn ptx_set_counting(ctx: *mut PtxContext, enabled: i32) -> i32;
+    pub fn ptx_reset_counters(ctx: *mut PtxContext) -> i32;
+    pub fn ptx_get_counters(ctx: *mut PtxContext, out: *mut PtxCounters) -> i32;
+    pub fn ptx_get_debug_stats(ctx: *mut PtxContext, out: *mut PtxDebugStats) -> i32;
+    pub fn ptx_set_profiling(ctx: *mut PtxContext, enabled: i32) -> i32;
+    pub fn ptx_reset_timings(ctx: *mut PtxContext) -> i32;
+    pub fn ptx_get_timings(ctx: *mut PtxContext, out: *mut PtxTimings) -> i32;
 }

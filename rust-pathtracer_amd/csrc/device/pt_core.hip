@@ -1249,6 +1249,7 @@ struct PtxContext {
     // `stream` (run_paths); ev_main / ev_side order the two streams
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    hipEvent_t ev_ext_in = nullptr, ev_ext_out = nullptr;     // ptx_order_after_stream / ptx_order_stream_after
     bool overlap_shadow = true;
     std::string err;
 
@@ -1931,6 +1932,8 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
         HIPCHK(hipMalloc((void**)&c->ovf_side, sizeof(uint2) * (size_t)std::max(MAX_TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
     }
+    HIPCHK(hipEventCreateWithFlags(&c->ev_ext_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_ext_out, hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * CTR_BLOCKS));
     HIPCHK(hipMalloc((void**)&c->ovf, sizeof(uint2) * (size_t)std::max(MAX_TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
     HIPCHK(hipMalloc((void**)&c->d_err, 4));
@@ -1957,6 +1960,8 @@ int32_t ptx_destroy(PtxContext* ctx) {
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
     if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
+    if (ctx->ev_ext_in) (void)hipEventDestroy(ctx->ev_ext_in);
+    if (ctx->ev_ext_out) (void)hipEventDestroy(ctx->ev_ext_out);
     if (ctx->ovf_side) (void)hipFree(ctx->ovf_side);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -2630,6 +2635,19 @@ int32_t ptx_fb_import_tiles_dev(PtxContext* ctx, const void* d_in, uint32_t src_
 }
 
 // ---- parity / measurement ------------------------------------------------------------------
+int32_t ptx_order_after_stream(PtxContext* ctx, void* stream) {
+    REQUIRE_CTX();
+    HIPCHK(hipEventRecord(ctx->ev_ext_in, static_cast<hipStream_t>(stream)));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_ext_in, 0));
+    return PTX_OK;
+}
+int32_t ptx_order_stream_after(PtxContext* ctx, void* stream) {
+    REQUIRE_CTX();
+    HIPCHK(hipEventRecord(ctx->ev_ext_out, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), ctx->ev_ext_out, 0));
+    return PTX_OK;
+}
+
 int32_t ptx_render_frame(PtxContext* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_bounces,
                          const PtxAdaptiveConfig* adaptive, uint32_t max_spp, float* out_mean, uint32_t* out_counts,
                          PtxFrameStats* out_stats) {

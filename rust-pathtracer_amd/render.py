@@ -24,6 +24,7 @@ EXPORTS = [
     "ptx_set_counting", "ptx_reset_counters", "ptx_get_counters", "ptx_set_profiling", "ptx_reset_timings",
     "ptx_get_timings", "ptx_debug_math", "ptx_render_frame", "ptx_fb_tonemap_srgb8", "ptx_fb_adaptive_passes",
     "ptx_get_debug_stats", "ptx_trace_batch_noalloc", "ptx_fb_tiles_bytes", "ptx_fb_export_tiles_dev", "ptx_fb_import_tiles_dev",
+    "ptx_order_after_stream", "ptx_order_stream_after",
 ]
 
 
@@ -80,6 +81,8 @@ def lib():
     L.ptx_fb_tiles_bytes.argtypes = [u32, u32, u32]
     L.ptx_fb_export_tiles_dev.argtypes = [vp, vp, u64]
     L.ptx_fb_import_tiles_dev.argtypes = [vp, vp, u32, u32]
+    L.ptx_order_after_stream.argtypes = [vp, vp]
+    L.ptx_order_stream_after.argtypes = [vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name == "ptx_fb_tiles_bytes":
@@ -393,17 +396,23 @@ class TileExchange:
         self.recv = torch.empty(self.nbytes * world, dtype=torch.uint8, device="cuda")
 
     def combine(self, fb):
+        """Export -> all-gather -> import, ordered by stream events only (`ptx_order_after_stream` /
+        `ptx_order_stream_after`): the host never waits, so the caller can enqueue the next frame behind it."""
         torch, L, h = self.torch, self.loop.L, self.loop._h
-        torch.cuda.current_stream().synchronize()      # the previous frame's collective no longer reads `send`
+        cur = torch.cuda.current_stream().cuda_stream      # hipStream_t of torch's current stream (0 = the default stream)
+        # the previous frame's collective (enqueued behind torch's stream) must no longer read `send`
+        self.loop._check(L.ptx_order_after_stream(h, cur), "ptx_order_after_stream")
         self.loop._check(L.ptx_fb_export_tiles_dev(h, self.send.data_ptr(), self.nbytes), "ptx_fb_export_tiles_dev")
-        self.loop.sync()                               # library stream -> visible to torch's stream
+        # the collective reads `send` after the export kernel on the library stream
+        self.loop._check(L.ptx_order_stream_after(h, cur), "ptx_order_stream_after")
         if self.host_staged:
             parts = [torch.empty(self.nbytes, dtype=torch.uint8) for _ in range(self.world)]
-            self.dist.all_gather(parts, self.send.cpu())
+            self.dist.all_gather(parts, self.send.cpu())          # .cpu() waits for torch's stream: gloo rehearsal only
             self.recv.copy_(torch.cat(parts))
         else:
-            self.dist.all_gather_into_tensor(self.recv, self.send)
-        torch.cuda.current_stream().synchronize()      # the library stream reads `recv` next
+            self.dist.all_gather_into_tensor(self.recv, self.send)      # RCCL over xGMI; torch orders it on its current stream
+        # the import kernels read `recv` after the collective
+        self.loop._check(L.ptx_order_after_stream(h, cur), "ptx_order_after_stream")
         for r in range(self.world):
             if r != self.rank:
                 self.loop._check(L.ptx_fb_import_tiles_dev(h, self.recv.data_ptr() + r * self.nbytes, r, self.world), "ptx_fb_import_tiles_dev")

@@ -76,7 +76,7 @@ for p in sorted(glob.glob(os.path.join(root, "pmc_*"))):
 
 
 # ---- --limiters OUT.json [--config JSON]: per kernel, what binds it, each figure recomputable from the table above ----
-def limiters(root, out_path, config, source):
+def limiters(root, out_path, config, source, frames=1):
     import json
     stats = {}
     f = find("trace", "kernel_trace.csv")
@@ -94,6 +94,12 @@ def limiters(root, out_path, config, source):
             k = short(r["Kernel_Name"])
             pmc[k][r["Counter_Name"]] = pmc[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     CLOCK_HZ, SIMDS, HBM_PEAK, L2_PEAK = 2.4e9, 1024, 8.0e12, 34.5e12      # MI355X_MICROARCH.md
+    # kernel durations inside the GRBM pass itself (counter collection serialises dispatches and changes timing a little)
+    grbm_ms = {}
+    fg = find("pmc_grbm", "kernel_trace.csv")
+    if fg:
+        for r in csv.DictReader(open(fg)):
+            grbm_ms[short(r["Kernel_Name"])] = grbm_ms.get(short(r["Kernel_Name"]), 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     out = {}
     for k, a in stats.items():
         c = pmc.get(k)
@@ -110,9 +116,18 @@ def limiters(root, out_path, config, source):
         if "TCC_REQ_sum" in c:
             e["l2_bw_frac"] = round(c["TCC_REQ_sum"] * 128 / t / L2_PEAK, 4)       # <= 128 B per request: upper bound
             e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+        clock = CLOCK_HZ
+        if "GRBM_GUI_ACTIVE" in c:
+            # rocprofv3 reports the sum over the 8 XCDs; per launch it reads high below ~0.3 ms, so take the kernel's total
+            # (MI355X_MICROARCH.md "DVFS give-back").  The pmc_grbm pass has its own timing: use that pass's durations.
+            t_g = grbm_ms.get(k, a["ms"]) * 1e-3
+            clock = c["GRBM_GUI_ACTIVE"] / 8.0 / t_g
+            e["clock_GHz_measured"] = round(clock / 1e9, 3)
         if "SQ_INSTS_VALU" in c:
-            # a wave64 VALU instruction occupies its SIMD-32 for 2 clocks; 1024 SIMDs at the 2.4 GHz peak clock
-            e["valu_issue_frac"] = round(c["SQ_INSTS_VALU"] * 2 / (SIMDS * CLOCK_HZ * t), 4)
+            # a wave64 VALU instruction occupies its SIMD-32 for 2 clocks; 1024 SIMDs at the clock measured in the same
+            # profile (GRBM_GUI_ACTIVE / 8 / kernel time), or the 2.4 GHz peak clock when that pass is missing
+            e["valu_issue_frac"] = round(c["SQ_INSTS_VALU"] * 2 / (SIMDS * clock * t), 4)
+            e["valu_issue_frac_at_peak_clock"] = round(c["SQ_INSTS_VALU"] * 2 / (SIMDS * CLOCK_HZ * t), 4)
         if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
             e["lanes_active"] = round(c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64), 4)
         if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
@@ -124,7 +139,7 @@ def limiters(root, out_path, config, source):
         if cand:
             e["binding"] = max(cand, key=cand.get)      # the throughput limit closest to its ceiling
         out[k] = e
-    json.dump({"config": config, "source": source, "peaks": {"hbm_Bps": HBM_PEAK, "l2_Bps": L2_PEAK, "simds": SIMDS, "clock_Hz": CLOCK_HZ},
+    json.dump({"config": config, "frames_profiled": frames, "source": source, "peaks": {"hbm_Bps": HBM_PEAK, "l2_Bps": L2_PEAK, "simds": SIMDS, "clock_Hz": CLOCK_HZ},
                "kernels": out}, open(out_path, "w"), indent=1)
 
 
@@ -133,4 +148,5 @@ if "--limiters" in sys.argv:
     i = sys.argv.index("--limiters")
     cfg = _json.loads(sys.argv[sys.argv.index("--config") + 1]) if "--config" in sys.argv else None
     src = sys.argv[sys.argv.index("--source") + 1] if "--source" in sys.argv else root
-    limiters(root, sys.argv[i + 1], cfg, src)
+    frames = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 1
+    limiters(root, sys.argv[i + 1], cfg, src, frames)
