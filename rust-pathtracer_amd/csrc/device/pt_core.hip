@@ -26,6 +26,7 @@
 
 #include "pt_shade.h"
 #include "pt_traverse.h"
+#include "pt_traverse_group.h"
 
 using namespace ptd;
 
@@ -297,6 +298,21 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S
     ExtendSink sink{P};
     trace_queue<false, CNT, FAST, UNC>(S, st, ctr->w_extend, n_active + n_walk, src, sink, lc, nrays, err, reinterpret_cast<unsigned long long*>(&dc->dbg[6]));
     if (CNT) flush_lane_cnt(dc, lc, nrays, false);
+}
+
+// Experiment (PTX_GROUP_LANES=4|8, DESIGN.md "G lanes per ray"): the closest-hit launches with G lanes per ray on the G-wide tree.
+template <int G>
+__global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend_group(SceneDev S, PathArrays P, const uint32_t* q, const uint32_t* q_walk, IterCtr* ctr, uint32_t* err) {
+    const uint32_t n_active = ctr->n_active, n_walk = ctr->n_walk;
+    ExtendSrc src{P, q, n_active, q_walk};
+    ExtendSink sink{P};
+    trace_groups<G>(S, ctr->w_extend, n_active + n_walk, src, sink, err);
+}
+template <int G>
+__global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_group(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits, uint32_t* work, uint32_t* err) {
+    BatchSrc src{rays};
+    BatchSink<false> sink{out_hits, nullptr};
+    trace_groups<G>(S, work, n, src, sink, err);
 }
 
 // Coherent queues (the primary rays of a wavefront batch): the wave's 64 rays walk the tree as one packet.
@@ -1291,6 +1307,7 @@ struct PtxContext {
     // (one record fetch serves 64 rays: primary launch 66 -> 60 ms at 8), the per-ray kernels lose (they are VALU-issue
     // bound and a wider record means more box tests per ray: extend 368 -> 402 ms at 4, 550 ms at 8 with 5 waves/SIMD)
     uint32_t packet_width = 8, ray_width = 0;     // PTX_WIDE_BVH, PTX_WIDE_RAY_BVH
+    uint32_t group_lanes = 0;       // PTX_GROUP_LANES = 4 | 8 (experiment): closest-hit launches with that many lanes per ray, on a tree that wide
     uint32_t adaptive_batch = 32;   // adaptive passes traced together by ptx_fb_adaptive_passes (PTX_ADAPTIVE_BATCH)
     bool adaptive_batch_auto = true;   // no PTX_ADAPTIVE_BATCH: start at 32 and double (up to 256) while >= 90 % of a batch's speculative samples were kept
     bool counting = false, profiling = false;
@@ -1794,6 +1811,12 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
             } else {
                 const bool fast = ctx->S.fast_on != 0u && !ctx->counting;
                 ScopedEvent ev(ctx, CLS_EXTEND);
+                if (ctx->group_lanes && !ctx->counting) {
+                    // 64 / G rays per wave: G times as many waves for the same queue
+                    const int gg = (int)std::min<uint64_t>(TRACE_GRID, ((uint64_t)n * ctx->group_lanes + TRACE_BLOCK - 1) / TRACE_BLOCK);
+                    if (ctx->group_lanes == 8) hipLaunchKernelGGL(k_extend_group<8>, dim3(gg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->d_err);
+                    else hipLaunchKernelGGL(k_extend_group<4>, dim3(gg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->d_err);
+                } else
                 if (ctx->counting && (ctx->S.fwd_on == 2u || (ctx->count_shipped && ctx->S.fwd_on)) && ctx->S.fast_on) {
                     // ptx_set_counting(ctx, 2) / PTX_COUNT_FORWARD=1: count what the shipped per-ray walk does (its node visits,
                     // triangle tests and entries, second attempts included) instead of what the reference's walk does
@@ -1911,6 +1934,10 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
     if (const char* e = std::getenv("PTX_PACKET_BATCH")) c->packet_batch = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("PTX_WIDE_BVH")) c->packet_width = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), 8);
     if (const char* e = std::getenv("PTX_WIDE_RAY_BVH")) c->ray_width = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), 8);
+    if (const char* e = std::getenv("PTX_GROUP_LANES")) {
+        const unsigned long v = std::strtoul(e, nullptr, 10);
+        if (v == 4 || v == 8) { c->group_lanes = (uint32_t)v; c->ray_width = (uint32_t)v; }
+    }
     if (const char* e = std::getenv("PTX_ADAPTIVE_BATCH")) {
         const unsigned long v = std::strtoul(e, nullptr, 10);
         if (v) { c->adaptive_batch = (uint32_t)std::min<unsigned long>(v, 256); c->adaptive_batch_auto = false; }
@@ -2697,6 +2724,10 @@ int32_t ptx_trace_batch(PtxContext* ctx, const PtxRay* rays, uint64_t n, int32_t
         } else if (mode == PTX_TRACE_ANY) {
             if (ctx->counting) hipLaunchKernelGGL((k_trace_batch<true, true>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
             else hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)nullptr, (uint8_t*)d_out, d_work, ctx->ovf, ctx->d_counters, ctx->d_err);
+        } else if (ctx->group_lanes && !ctx->counting) {
+            const int gg = (int)std::min<uint64_t>(TRACE_GRID, (n * ctx->group_lanes + TRACE_BLOCK - 1) / TRACE_BLOCK);
+            if (ctx->group_lanes == 8) hipLaunchKernelGGL(k_trace_group<8>, dim3(gg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, d_work, ctx->d_err);
+            else hipLaunchKernelGGL(k_trace_group<4>, dim3(gg), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, d_work, ctx->d_err);
         } else if (ctx->packet_batch && !ctx->counting) {
             hipLaunchKernelGGL(k_trace_batch_packet<false>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, d_rays, (uint32_t)n, (PtxHitRecord*)d_out, (uint8_t*)nullptr, d_work, ctx->ovf, ctx->d_err, ctx->d_counters);
         } else {
