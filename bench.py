@@ -288,19 +288,24 @@ def main():
     # configuration (otherwise a Cornell run would carry Bistro's traffic)
     this_config = {"scene": args.scene, "detail": args.detail, "width": w, "height": h, "spp": spp, "bounces": args.bounces,
                    "flags": args.flags, "seed": args.seed, "world": world}
-    lim_file = os.path.join(ROOT, "profiles", "r02_limiters.json")
+    lim_file = os.path.join(ROOT, "profiles", "r03_limiters.json")
     if os.path.exists(lim_file):
         try:
             lim = json.load(open(lim_file))
             kernels = lim.get("kernels", {})
-            k = kernels.get("k_extend<false, true>") or kernels.get("k_extend<false, false>") or kernels.get("k_extend<false>")   # nearest-first / reference-order instantiation
+            want = "k_extend<false, true" if verify["nearest_first"] else "k_extend<false, false"      # nearest-first / reference-order instantiation
+            k = next((v for n, v in kernels.items() if n.startswith(want)), None)
             if lim.get("config") == this_config and k:
                 roofline["traffic"] = k["hbm_bytes_per_launch"]
                 # counter bytes over THIS run's launch time
                 roofline["measured_hbm_frac"] = round(k["hbm_bytes_per_launch"] / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                roofline["limiters"] = {n: k[n] for n in ("hbm_traffic_frac", "l2_bw_frac", "valu_issue_frac", "lanes_active",
-                                                         "mem_wait_share", "binding") if n in k}
+                roofline["limiters"] = {n: k[n] for n in ("hbm_traffic_frac", "l2_bw_frac", "l2_hit_rate", "valu_issue_frac", "valu_issue_frac_at_peak_clock",
+                                                         "clock_GHz_measured", "lanes_active", "mem_wait_share", "issue_wait_share", "salu_per_valu", "binding") if n in k}
                 roofline["limiters"]["source"] = lim.get("source")
+                # what actually binds the kernel (the contract's `bound` stays "hbm": achieved / peak are bytes per second)
+                roofline["binding_limiter"] = {"name": k.get("binding"), "frac": k.get(k.get("binding", ""), None),
+                                               "clock_GHz": k.get("clock_GHz_measured"),
+                                               "note": "VALU issue: wave64 VALU instructions x 2 clocks / (1024 SIMDs x the clock measured in the same profile, GRBM_GUI_ACTIVE / 8 / kernel time)"}
         except Exception as e:      # a malformed profile file must not fail the bench
             roofline["limiters_error"] = str(e)
 

@@ -302,14 +302,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend(SceneDev S
 
 // Experiment (PTX_GROUP_LANES=4|8, DESIGN.md "G lanes per ray"): the closest-hit launches with G lanes per ray on the G-wide tree.
 template <int G>
-__global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_extend_group(SceneDev S, PathArrays P, const uint32_t* q, const uint32_t* q_walk, IterCtr* ctr, uint32_t* err) {
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void k_extend_group(SceneDev S, PathArrays P, const uint32_t* q, const uint32_t* q_walk, IterCtr* ctr, uint32_t* err) {
     const uint32_t n_active = ctr->n_active, n_walk = ctr->n_walk;
     ExtendSrc src{P, q, n_active, q_walk};
     ExtendSink sink{P};
     trace_groups<G>(S, ctr->w_extend, n_active + n_walk, src, sink, err);
 }
 template <int G>
-__global__ __launch_bounds__(TRACE_BLOCK) PT_TRACE_ATTR void k_trace_group(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits, uint32_t* work, uint32_t* err) {
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void k_trace_group(SceneDev S, const PtxRay* rays, uint32_t n, PtxHitRecord* out_hits, uint32_t* work, uint32_t* err) {
     BatchSrc src{rays};
     BatchSink<false> sink{out_hits, nullptr};
     trace_groups<G>(S, work, n, src, sink, err);

@@ -10,7 +10,8 @@ export TMPDIR=/tmp
 # one stream: every kernel's duration is then its own (by default the any-hit launch shares the GPU with the next
 # closest-hit launch and its dispatch time includes waiting for wave slots; k_extend's own duration is the same either way)
 export PTX_OVERLAP_SHADOW=0
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --spp 64 $*"
+# --no-order-check: the untimed reference-order frame would add a second frame of k_shade / k_shadow launches to the sums
+ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-order-check --spp 64 $*"
 run() { # name, then rocprofv3 options
   local name=$1; shift
   timeout -s KILL 420 rocprofv3 "$@" -d "$OUT/$name" --output-format csv -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1
