@@ -56,6 +56,12 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    # frames kept in flight during the timed region: 2 = two contexts render alternate frames (ptx_fb_render_passes_async +
+    # ptx_order_after_frame_tail), so the latency-bound last iterations of one frame share the GPU with the first iterations
+    # of the next; 1 = one frame at a time (default).  Measured: no gain on a whole frame per GPU (564.3 vs
+    # 564.5 ms), 83.5 -> 80.4 ms on an eighth of the frame (predicted 8-GPU efficiency 0.84 -> 0.88); the per-kernel event
+    # times of overlapping frames are no longer each kernel's own, so the roofline line is quoted with 1.
+    ap.add_argument("--frames-in-flight", type=int, default=1, choices=(1, 2))
     ap.add_argument("--no-order-check", action="store_true")   # skip the untimed reference-order frame (kernel experiments only)
     # one-GPU prediction of an N-GPU frame: render every rank's tile partition in turn on this card (no collective)
     ap.add_argument("--emulate-world", type=int, default=0)
@@ -112,18 +118,32 @@ def main():
     loop._bind(scene, cam)   # upload once: inputs are resident in HBM before anything is timed
     note(f"scene built in {build_s:.1f} s and uploaded")
 
-    exchange = pkg.render.TileExchange(dist, loop, w, h, rank, world, host_staged=(backend != "nccl")) if world > 1 else None
+    # contexts that render alternate frames of the timed region (each with its own path state, queues, streams and framebuffer)
+    nfl = args.frames_in_flight if args.steps > 1 else 1
+    loops, fbs = [loop], [fb]
+    for _ in range(1, nfl):
+        lp_k = pkg.HipRenderLoop(local_rank)
+        lp_k.set_partition(rank, world)
+        fbs.append(pkg.DeviceFramebuffer(lp_k, w, h, adaptive=True))
+        lp_k._bind(scene, cam)
+        loops.append(lp_k)
+    exchanges = [pkg.render.TileExchange(dist, lp_k, w, h, rank, world, host_staged=(backend != "nccl")) for lp_k in loops] if world > 1 else None
 
-    def frame(r=None):
-        fb.reset()
-        fb.render_passes(scene, cam, r or renderer, 0, spp)
+    def frame(r=None, k=0, wait=True):
+        if nfl > 1:
+            # this context's frame starts when the other context's frame is past its heavy iterations: the two frames'
+            # big launches do not compete, the other frame's latency-bound tail runs beside this frame's start
+            loops[k].order_after_frame_tail(loops[1 - k])
+        fbs[k].reset()
+        fbs[k].render_passes(scene, cam, r or renderer, 0, spp, wait=wait)
         if world > 1:
             # the one exchange step of the frame: all-gather of every rank's owned tiles (RCCL over xGMI), scattered
             # into each rank's framebuffer, which then holds the whole frame (bit-identical to the 1-GPU frame)
-            exchange.combine(fb)
+            exchanges[k].combine(fbs[k])
 
     def fence():
-        loop.sync()
+        for lp_k in loops:
+            lp_k.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -156,21 +176,31 @@ def main():
     loop.set_counting(0)
     note("counted frames done")
 
-    for _ in range(args.warmup):
-        frame()
+    for i in range(args.warmup):
+        frame(k=i % nfl)
         note("warm-up frame done")
+    if args.warmup:
+        for k in range(args.warmup, nfl):       # every context has rendered once before the clock starts (its allocations are made)
+            frame(k=k)
     fence()
     note("fenced")
-    loop.set_profiling(True)
-    loop.reset_timings()
+    for lp_k in loops:
+        lp_k.reset_counters()
+        lp_k.set_profiling(True)
+        lp_k.reset_timings()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame()
+    for i in range(args.steps):
+        frame(k=i % nfl, wait=(nfl == 1))
     fence()
     elapsed = time.perf_counter() - t0
     note(f"timed region {elapsed:.3f} s")
-    tim = loop.timings()
-    loop.set_profiling(False)
+    tim = {}
+    for lp_k in loops:                          # HIP events of every context's launches
+        for key, v in lp_k.timings().items():
+            tim[key] = tim.get(key, 0) + v
+        lp_k.set_profiling(False)
+    fb = fbs[(args.steps - 1) % nfl]            # the last timed frame is the one that checks itself below
+    loop_last = loops[(args.steps - 1) % nfl]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -195,13 +225,14 @@ def main():
     # what the forwarded bound and the nearest-first walk presume, measured on this run: how far a computed
     # triangle hit lay in front of its leaf box at most (counted frame, relative), and how many closest-hit rays of the
     # timed frames were traced a second time in reference order
-    dbg_timed = loop.debug_stats()
+    dbg_timed = loop_last.debug_stats()
+    dbg_timed["fast_redo_rays"] = sum(lp_k.debug_stats()["fast_redo_rays"] for lp_k in loops)
     verify["max_leaf_undershoot"] = float(f"{dbg_counted['max_leaf_undershoot']:.3e}")
     verify["max_leaf_undershoot_beyond_slack"] = float(f"{dbg_counted['max_leaf_undershoot_excess']:.3e}")
     verify["undershoot_tolerated"] = {"forwarded_bound": 2.0 ** -5, "nearest_first": 2.0 ** -10}
     verify["bound_forwarding"] = int(dbg_timed["bound_forwarding"])
     verify["nearest_first"] = int(dbg_timed["fast_order"])
-    verify["second_attempt_rays_per_frame"] = int(dbg_timed["fast_redo_rays"] // max(1, args.steps + args.warmup))
+    verify["second_attempt_rays_per_frame"] = int(dbg_timed["fast_redo_rays"] // max(1, args.steps))
     verify["uncertified_meshes"] = int(dbg_timed["uncertified_meshes"])
     if not (verify["counts_eq_spp"] and verify["finite"] and verify["clamped"]):
         raise SystemExit(f"bench.py: the timed frame failed its own checks: {verify}")
@@ -317,7 +348,8 @@ def main():
         "config": {"workload": f"{args.scene} (procedural stand-in, seed {args.seed}, detail {args.detail}) "
                                f"{w}x{h} {spp}spp PathTracer<{args.bounces}> env-map IS + sun + MIS, tile-interleaved over {world} GPU(s)",
                    "triangles": scene.stats()["triangles"], "instances": scene.stats()["instances"],
-                   "parallelism": f"tiles8x8 mod {world}" + (" + one RCCL all-gather of owned tiles per frame" if world > 1 else "")},
+                   "parallelism": f"tiles8x8 mod {world}" + (" + one RCCL all-gather of owned tiles per frame" if world > 1 else ""),
+                   "frames_in_flight": nfl},
         "sec_per_frame": round(sec_per_frame, 4),
         "mprimary_per_s": round(primary_per_frame / sec_per_frame / 1e6, 2),
         "rays_per_frame": rays_per_frame,
@@ -337,7 +369,7 @@ def main():
     }
 
     if world == 1 and args.emulate_world > 1:
-        out["emulated_world"] = emulate_world(pkg, loop, fb, scene, cam, renderer, spp, args, sec_per_frame)
+        out["emulated_world"] = emulate_world(pkg, loops, fbs, scene, cam, renderer, spp, args, sec_per_frame)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, scene, cam, w, h, args.bounces, args.cpu_seconds)
     if rank == 0:
@@ -346,24 +378,39 @@ def main():
         dist.destroy_process_group()
 
 
-def emulate_world(pkg, loop, fb, scene, cam, renderer, spp, args, sec_one_gpu):
+def emulate_world(pkg, loops, fbs, scene, cam, renderer, spp, args, sec_one_gpu):
     """What an N-GPU frame would cost, measured on ONE card: each rank's partition (8x8 tiles, tile % N == rank) is
     rendered in turn with everything else as in the real run.  Ranks do not talk during a frame (the exchange is one
     all-gather at the end), so the N-GPU frame time is the slowest rank's time plus the exchange.
       load balance          max / mean of the rank times
       short-queue overhead  sum of the rank times / the 1-GPU frame time (a rank's queues are N times shorter)
-      adaptive frames       per-rank adaptive sample counts: how evenly the interleave spreads the noisy pixels"""
+      adaptive frames       per-rank adaptive sample counts: how evenly the interleave spreads the noisy pixels
+    Uniform frames are timed the way the bench times them: `len(loops)` contexts render alternate frames, 4 frames per
+    rank, time per frame = total / 4 (with one context that is one frame at a time)."""
     n = args.emulate_world
     w, h = args.width, args.height
     cfg = pkg.AdaptiveSamplingConfig(64, 0.001) if args.adaptive_cap > spp else None      # app.rs:139-143
     times, adaptive_samples, passes = [], [], []
+    loop, fb = loops[0], fbs[0]
+    nfl = len(loops) if cfg is None else 1
 
     def one(rank_):
-        loop.set_partition(rank_, n)
+        if cfg is not None:
+            loop.set_partition(rank_, n)
+            t0 = time.perf_counter()
+            r, p = pkg.render.render_frame_distributed(lambda v: int(v), loop, fb, scene, cam, renderer, spp, adaptive=cfg, max_spp=args.adaptive_cap)
+            loop.sync()
+            return time.perf_counter() - t0, r, p
+        reps = 4
         t0 = time.perf_counter()
-        r, p = pkg.render.render_frame_distributed(lambda v: int(v), loop, fb, scene, cam, renderer, spp, adaptive=cfg, max_spp=args.adaptive_cap)
-        loop.sync()
-        return time.perf_counter() - t0, r, p
+        for i in range(reps):
+            if nfl > 1:
+                loops[i % nfl].order_after_frame_tail(loops[1 - i % nfl])
+            fbs[i % nfl].reset()
+            fbs[i % nfl].render_passes(scene, cam, renderer, 0, spp, wait=(nfl == 1))
+        for lp_k in loops[:nfl]:
+            lp_k.sync()
+        return (time.perf_counter() - t0) / reps, 0, 0
 
     try:
         full_t = None
@@ -373,16 +420,19 @@ def emulate_world(pkg, loop, fb, scene, cam, renderer, spp, args, sec_one_gpu):
             one_()
             t0 = time.perf_counter(); one_(); full_t = time.perf_counter() - t0
         for r_ in range(n):
+            for lp_k in loops[:nfl]:
+                lp_k.set_partition(r_, n)
             one(r_)                   # warm-up: work list and path state for this partition
             dt, rendered, p = one(r_)
             times.append(dt); adaptive_samples.append(rendered); passes.append(p)
     finally:
-        loop.set_partition(0, 1)
+        for lp_k in loops:
+            lp_k.set_partition(0, 1)
     ref = full_t if full_t is not None else sec_one_gpu
     exch_bytes = pkg.render.tiles_bytes(w, h, n) * (n - 1)            # what one rank receives in the all-gather
     exch_s = exch_bytes / 153e9                                       # one xGMI link (point-to-point, ~153 GB/s): pessimistic, 7 links can run in parallel
     mx, mean = max(times), sum(times) / n
-    return {"world": n, "rank_s": [round(t, 4) for t in times], "max_over_mean": round(mx / mean, 4),
+    return {"world": n, "frames_in_flight": nfl, "rank_s": [round(t, 4) for t in times], "max_over_mean": round(mx / mean, 4),
             "sum_over_one_gpu_frame": round(sum(times) / ref, 4), "one_gpu_frame_s": round(ref, 4),
             "exchange_bytes_received_per_rank": exch_bytes, "exchange_s_one_link": round(exch_s, 6),
             "predicted_frame_s": round(mx + exch_s, 4), "predicted_speedup": round(ref / (mx + exch_s), 3),

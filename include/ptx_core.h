@@ -306,6 +306,19 @@ int32_t ptx_fb_reset(PtxContext* ctx, uint32_t width, uint32_t height, int32_t a
  * (main.rs:124-133, framebuffer.rs:44-50, 118-125).  Nothing leaves the GPU. */
 int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t count,
                              uint32_t max_bounces);
+/* The same, returning as soon as the work is enqueued on the library's streams (no counterpart in the reference, which is
+ * synchronous): a traversal stack overflow is then reported by the next call that synchronises (ptx_sync, ptx_fb_stats,
+ * ptx_fb_read*, ptx_fb_tonemap_srgb8) instead of by this one.  Lets a host keep several frames in flight — e.g. two
+ * contexts rendering alternate frames, so that the latency-bound last iterations of one frame share the GPU with the
+ * first iterations of the next (bench.py --frames-in-flight).  Scenes with subsurface materials still poll the device
+ * every few iterations (their iteration count is data dependent). */
+int32_t ptx_fb_render_passes_async(PtxContext* ctx, uint32_t first_sample, uint32_t count, uint32_t max_bounces);
+/* Two contexts on one GPU rendering alternate frames: everything `ctx` enqueues from now on starts after `other`'s most
+ * recent ptx_fb_render_passes* call has got past its heavy iterations (the launches of its first three path-tracing
+ * iterations per wavefront batch; PTX_TAIL_GATE_ITER).  The latency-bound last iterations of `other`'s frame then share
+ * the GPU with the first iterations of `ctx`'s next frame instead of leaving it idle, without the two frames' heavy
+ * launches competing.  No counterpart in the reference; a no-op if `other` has not rendered yet. */
+int32_t ptx_order_after_frame_tail(PtxContext* ctx, PtxContext* other);
 
 /* `render_adaptive_pass` (renderloop/parallel.rs:80-123) incl.
  * `get_noisy_pixels` (framebuffer.rs:181-214); returns the work-list length. */

@@ -251,6 +251,8 @@ extern "C" {
     pub fn ptx_render_pass_unshaded(ctx: *mut PtxContext, w: u32, h: u32, sample_index: u32, out_rgb: *mut f32) -> i32;
     pub fn ptx_fb_reset(ctx: *mut PtxContext, w: u32, h: u32, adaptive: i32) -> i32;
     pub fn ptx_fb_render_passes(ctx: *mut PtxContext, first_sample: u32, count: u32, max_bounces: u32) -> i32;
+    /// The same without the final device-error readback: returns once the work is enqueued (errors surface at the next synchronising call).
+    pub fn ptx_fb_render_passes_async(ctx: *mut PtxContext, first_sample: u32, count: u32, max_bounces: u32) -> i32;
     pub fn ptx_fb_adaptive_pass(ctx: *mut PtxContext, cfg: *const PtxAdaptiveConfig, max_bounces: u32, out_rendered: *mut u64) -> i32;
     pub fn ptx_fb_adaptive_passes(ctx: *mut PtxContext, cfg: *const PtxAdaptiveConfig, max_bounces: u32, max_passes: u32, out_passes: *mut u32, out_rendered: *mut u64) -> i32;
     pub fn ptx_fb_stats(ctx: *mut PtxContext, out_min: *mut u32, out_max: *mut u32, out_total: *mut u64) -> i32;
@@ -267,6 +269,8 @@ extern "C" {
     pub fn ptx_fb_tiles_bytes(width: u32, height: u32, world: u32) -> u64;
     pub fn ptx_fb_export_tiles_dev(ctx: *mut PtxContext, d_out: *mut core::ffi::c_void, capacity_bytes: u64) -> i32;
     pub fn ptx_fb_import_tiles_dev(ctx: *mut PtxContext, d_in: *const core::ffi::c_void, src_rank: u32, world: u32) -> i32;
+    /// Two contexts rendering alternate frames on one GPU: `ctx` starts after `other`'s frame is past its heavy iterations.
+    pub fn ptx_order_after_frame_tail(ctx: *mut PtxContext, other: *mut PtxContext) -> i32;
     /// Stream ordering without a host stall: the library after `stream`'s enqueued work / `stream` after the library's.
     pub fn ptx_order_after_stream(ctx: *mut PtxContext, stream: *mut core::ffi::c_void) -> i32;
     pub fn ptx_order_stream_after(ctx: *mut PtxContext, stream: *mut core::ffi::c_void) -> i32;

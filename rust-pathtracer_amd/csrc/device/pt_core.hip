@@ -1266,6 +1266,8 @@ struct PtxContext {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     hipEvent_t ev_ext_in = nullptr, ev_ext_out = nullptr;     // ptx_order_after_stream / ptx_order_stream_after
+    hipEvent_t ev_tail = nullptr;       // recorded once a frame's heavy iterations are enqueued (ptx_order_after_frame_tail)
+    uint32_t tail_gate_iter = 3;        // PTX_TAIL_GATE_ITER
     bool overlap_shadow = true;
     std::string err;
 
@@ -1790,6 +1792,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
     bool drained = false;
     const bool side = ctx->overlap_shadow && !ctx->counting && ctx->side_stream != nullptr;
     bool side_pending = false;      // work on the side stream the main stream has not been ordered behind yet
+    bool tail_recorded = false;     // ev_tail: "the heavy iterations of this batch are enqueued" (ptx_order_after_frame_tail)
     // An early return below (a failed HIP call, the subsurface poll, a packet launch) must not leave side-stream kernels
     // running behind the caller's next main-stream call: they still write P and the framebuffer.
     struct SideJoin {
@@ -1830,6 +1833,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
                 else hipLaunchKernelGGL((k_extend<false, false>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
             }
         }
+        if (it == ctx->tail_gate_iter) { HIPCHK(hipEventRecord(ctx->ev_tail, ctx->stream)); tail_recorded = true; }
         // iteration it - 1's any-hit launch (side stream) zeroes the pending terms this k_shade adds, and reads the shadow
         // and final queues this k_shade overwrites
         if (side && it > 0) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0)); side_pending = false; }
@@ -1882,6 +1886,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
     // whatever follows on the main stream (accumulation, readbacks, the next batch's k_raygen) comes after the side stream's work
     if (side_pending) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
     side_join.armed = false;        // joined through the event: no host wait on the normal road
+    if (!tail_recorded) HIPCHK(hipEventRecord(ctx->ev_tail, ctx->stream));      // a batch with fewer iterations than the gate
     HIPCHK(hipGetLastError());
     // Without SSS every path ends by iteration max_bounces (k_shade retires it at bounce >= max_bounces).  With SSS a
     // path that is still walking after MAX_ITERS - 1 iterations would never reach k_finalize: refuse instead of
@@ -1959,6 +1964,8 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
         HIPCHK(hipMalloc((void**)&c->ovf_side, sizeof(uint2) * (size_t)std::max(MAX_TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
     }
+    HIPCHK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    if (const char* e = std::getenv("PTX_TAIL_GATE_ITER")) c->tail_gate_iter = (uint32_t)std::strtoul(e, nullptr, 10);
     HIPCHK(hipEventCreateWithFlags(&c->ev_ext_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_ext_out, hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * CTR_BLOCKS));
@@ -1987,6 +1994,7 @@ int32_t ptx_destroy(PtxContext* ctx) {
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
     if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
+    if (ctx->ev_tail) (void)hipEventDestroy(ctx->ev_tail);
     if (ctx->ev_ext_in) (void)hipEventDestroy(ctx->ev_ext_in);
     if (ctx->ev_ext_out) (void)hipEventDestroy(ctx->ev_ext_out);
     if (ctx->ovf_side) (void)hipFree(ctx->ovf_side);
@@ -2406,7 +2414,7 @@ int32_t ptx_fb_reset(PtxContext* ctx, uint32_t w, uint32_t h, int32_t adaptive) 
 
 #define REQUIRE_FB() do { REQUIRE_CAMERA(); if (!ctx->fb_sum) return fail(ctx, PTX_ERR_INVALID, "no framebuffer: call ptx_fb_reset"); } while (0)
 
-int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t count, uint32_t max_bounces) {
+static int32_t fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t count, uint32_t max_bounces, bool check) {
     REQUIRE_FB();
     int32_t st = ensure_worklist(ctx, ctx->fb_w, ctx->fb_h);
     if (st != PTX_OK) return st;
@@ -2434,7 +2442,14 @@ int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t co
     }
     add_primary_count(ctx, (uint64_t)ctx->wl_n * count);
     // a traversal that ran out of stack ends its ray early (less work, a faster frame): never hand that back as OK
-    return check_device_error(ctx);
+    // (the async form leaves that to the next synchronising call: ptx_sync, ptx_fb_stats, ptx_fb_read*)
+    return check ? check_device_error(ctx) : PTX_OK;
+}
+int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t count, uint32_t max_bounces) {
+    return fb_render_passes(ctx, first_sample, count, max_bounces, true);
+}
+int32_t ptx_fb_render_passes_async(PtxContext* ctx, uint32_t first_sample, uint32_t count, uint32_t max_bounces) {
+    return fb_render_passes(ctx, first_sample, count, max_bounces, false);
 }
 
 int32_t ptx_fb_adaptive_pass(PtxContext* ctx, const PtxAdaptiveConfig* cfg, uint32_t max_bounces, uint64_t* out_rendered) {
@@ -2662,6 +2677,13 @@ int32_t ptx_fb_import_tiles_dev(PtxContext* ctx, const void* d_in, uint32_t src_
 }
 
 // ---- parity / measurement ------------------------------------------------------------------
+int32_t ptx_order_after_frame_tail(PtxContext* ctx, PtxContext* other) {
+    REQUIRE_CTX();
+    if (!other || other == ctx) return fail(ctx, PTX_ERR_INVALID, "needs another context");
+    if (other->device != ctx->device) return fail(ctx, PTX_ERR_INVALID, "contexts are on different devices");
+    HIPCHK(hipStreamWaitEvent(ctx->stream, other->ev_tail, 0));     // an event never recorded is complete: no-op
+    return PTX_OK;
+}
 int32_t ptx_order_after_stream(PtxContext* ctx, void* stream) {
     REQUIRE_CTX();
     HIPCHK(hipEventRecord(ctx->ev_ext_in, static_cast<hipStream_t>(stream)));

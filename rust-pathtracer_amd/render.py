@@ -24,7 +24,7 @@ EXPORTS = [
     "ptx_set_counting", "ptx_reset_counters", "ptx_get_counters", "ptx_set_profiling", "ptx_reset_timings",
     "ptx_get_timings", "ptx_debug_math", "ptx_render_frame", "ptx_fb_tonemap_srgb8", "ptx_fb_adaptive_passes",
     "ptx_get_debug_stats", "ptx_trace_batch_noalloc", "ptx_fb_tiles_bytes", "ptx_fb_export_tiles_dev", "ptx_fb_import_tiles_dev",
-    "ptx_order_after_stream", "ptx_order_stream_after",
+    "ptx_order_after_stream", "ptx_order_stream_after", "ptx_fb_render_passes_async", "ptx_order_after_frame_tail",
 ]
 
 
@@ -58,6 +58,7 @@ def lib():
     L.ptx_render_pass_unshaded.argtypes = [vp, u32, u32, u32, vp]
     L.ptx_fb_reset.argtypes = [vp, u32, u32, i32]
     L.ptx_fb_render_passes.argtypes = [vp, u32, u32, u32]
+    L.ptx_fb_render_passes_async.argtypes = [vp, u32, u32, u32]
     L.ptx_fb_adaptive_pass.argtypes = [vp, C.POINTER(abi.PtxAdaptiveConfig), u32, C.POINTER(u64)]
     L.ptx_fb_adaptive_passes.argtypes = [vp, C.POINTER(abi.PtxAdaptiveConfig), u32, u32, C.POINTER(u32), C.POINTER(u64)]
     L.ptx_fb_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
@@ -82,6 +83,7 @@ def lib():
     L.ptx_fb_export_tiles_dev.argtypes = [vp, vp, u64]
     L.ptx_fb_import_tiles_dev.argtypes = [vp, vp, u32, u32]
     L.ptx_order_after_stream.argtypes = [vp, vp]
+    L.ptx_order_after_frame_tail.argtypes = [vp, vp]
     L.ptx_order_stream_after.argtypes = [vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -161,6 +163,11 @@ class HipRenderLoop:
 
     def set_partition(self, rank, world):
         self._check(self.L.ptx_set_partition(self._h, rank, world), "ptx_set_partition")
+
+    def order_after_frame_tail(self, other):
+        """Everything this loop enqueues from now on starts after `other`'s current frame is past its heavy iterations
+        (`ptx_order_after_frame_tail`): two loops rendering alternate frames keep the GPU busy through each other's tails."""
+        self._check(self.L.ptx_order_after_frame_tail(self._h, other._h), "ptx_order_after_frame_tail")
 
     def sync(self):
         self._check(self.L.ptx_sync(self._h), "ptx_sync")
@@ -459,9 +466,14 @@ class DeviceFramebuffer:
     def reset(self):
         self.loop._check(self.loop.L.ptx_fb_reset(self.loop._h, self.width, self.height, 1 if self.adaptive else 0), "ptx_fb_reset")
 
-    def render_passes(self, scene, camera, renderer, first_sample, count):
+    def render_passes(self, scene, camera, renderer, first_sample, count, wait=True):
+        """wait=False: `ptx_fb_render_passes_async` — returns once the work is enqueued; errors surface at the next
+        synchronising call (`loop.sync()`, `stats()`, `read()`)."""
         self.loop._bind(scene, camera)
-        self.loop._check(self.loop.L.ptx_fb_render_passes(self.loop._h, first_sample, count, renderer.max_bounces), "ptx_fb_render_passes")
+        if wait:
+            self.loop._check(self.loop.L.ptx_fb_render_passes(self.loop._h, first_sample, count, renderer.max_bounces), "ptx_fb_render_passes")
+        else:
+            self.loop._check(self.loop.L.ptx_fb_render_passes_async(self.loop._h, first_sample, count, renderer.max_bounces), "ptx_fb_render_passes_async")
 
     def stats(self):
         mn, mx, tot = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
