@@ -77,3 +77,41 @@ def test_rccl_exchange_orders_itself_by_stream_events(pkg, tmp_path):
     assert want.nbytes == pkg.render.tiles_bytes(w, h, 1) == d["recv"].nbytes
     assert int(d["c"].min()) == int(d["c"].max()) == 4          # the second frame, not a mixture
     assert np.array_equal(d["recv"].view(np.uint32).reshape(-1, 7), want)
+
+
+def test_two_contexts_rendering_alternate_frames_change_nothing(pkg):
+    """`ptx_fb_render_passes_async` + `ptx_order_after_frame_tail` (bench.py --frames-in-flight 2): two contexts on one
+    GPU render alternate frames, each starting once the other's frame is past its heavy iterations, with no host wait in
+    between.  Every frame must be the frame one context renders alone, bit for bit (the map being pipelined is the
+    `for sample` loop of /root/reference/src/main.rs:123-141, one frame after the other there)."""
+    sc = pkg.Scene.procedural("sponza_like", 1, 0.1, 1)
+    w, h, spp = 320, 184, 6
+    cam = sc.default_camera(w / h)
+    r = pkg.PathTracer(8)
+    solo = pkg.HipRenderLoop(0)
+    fb0 = pkg.DeviceFramebuffer(solo, w, h, adaptive=True)
+    want = []
+    for first in (0, 6, 12, 18):
+        fb0.reset()
+        fb0.render_passes(sc, cam, r, first, spp)
+        want.append([a.copy() for a in fb0.read()])
+    loops = [pkg.HipRenderLoop(0), pkg.HipRenderLoop(0)]
+    fbs = [pkg.DeviceFramebuffer(lp, w, h, adaptive=True) for lp in loops]
+    got = []
+    for i, first in enumerate((0, 6, 12, 18)):
+        k = i % 2
+        if i >= 2:      # this context's previous frame: read it before it is overwritten (that read synchronises this context only)
+            got.append([a.copy() for a in fbs[k].read()])
+        loops[k].order_after_frame_tail(loops[1 - k])
+        fbs[k].reset()
+        fbs[k].render_passes(sc, cam, r, first, spp, wait=False)
+    for k in (0, 1):
+        loops[k].sync()
+        got.append([a.copy() for a in fbs[k].read()])
+    assert len(got) == 4
+    for i in range(4):
+        for a, b in zip(got[i], want[i]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
+    # a context cannot wait for itself, nor for a context that does not exist
+    with pytest.raises(pkg.render.RenderCoreError):
+        loops[0].order_after_frame_tail(loops[0])
