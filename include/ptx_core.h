@@ -252,6 +252,10 @@ typedef struct PtxTimings {
     /* the subsurface random-walk kernel (one launch per iteration in scenes with subsurface materials) */
     double walk_ms;
     uint64_t walk_launches;
+    /* the tail kernel: the late iterations of a batch, all phases in one launch (closest hit, shading, walk steps,
+     * any hit, accumulation of the paths it carries are in here, not in the lines above) */
+    double tail_ms;
+    uint64_t tail_launches;
 } PtxTimings;
 
 typedef struct PtxContext PtxContext;

@@ -207,6 +207,8 @@ pub struct PtxTimings {
     pub packet_launches: u64,
     pub walk_ms: f64,
     pub walk_launches: u64,
+    pub tail_ms: f64,
+    pub tail_launches: u64,
 }
 
 /// Which traversal roads the launches since `ptx_reset_counters` took (stack high-water marks, packet redo, the

@@ -166,6 +166,7 @@ class PtxTimings(C.Structure):
         ("extend_launches", c_u64), ("shade_launches", c_u64), ("shadow_launches", c_u64),
         ("packet_ms", C.c_double), ("packet_launches", c_u64),
         ("walk_ms", C.c_double), ("walk_launches", c_u64),
+        ("tail_ms", C.c_double), ("tail_launches", c_u64),
     ]
 
 

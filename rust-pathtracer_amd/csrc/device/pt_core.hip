@@ -64,7 +64,7 @@ constexpr uint32_t MAX_ITERS = 4096;
 // counter blocks past the per-iteration range [0, MAX_ITERS): one per helper, so none aliases an iteration's block or
 // another helper's
 constexpr uint32_t CTR_REDO = MAX_ITERS, CTR_STATS = MAX_ITERS + 1, CTR_BATCH = MAX_ITERS + 2, CTR_ADAPTIVE = MAX_ITERS + 3,
-                   CTR_BLOCKS = MAX_ITERS + 4;
+                   CTR_TAIL = MAX_ITERS + 4, CTR_BLOCKS = MAX_ITERS + 5;
 // P.rad[].w = pixel index | which pending contributions of the previous step are stored (an absent one is +0.0: it is
 // neither written nor read back, which is most of them — the BSDF-sampled sun term almost always, the NEE terms whenever
 // the light is below the surface)
@@ -444,16 +444,15 @@ PT_DEV bool walk_begin_step(const PtxMaterial& material, V3 wt, float w_scale, R
 #define PT_WALK_BLOCK 256
 #endif
 constexpr int WALK_BLOCK = PT_WALK_BLOCK;
-template <bool CNT>
-__global__ __launch_bounds__(WALK_BLOCK) void k_sss_step(SceneDev S, PathArrays P, const uint32_t* q_walk, uint32_t* q_walk_next, uint32_t* q_next,
-                                                         uint32_t* q_shadow, uint32_t* q_final, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
-                                                         DevCounters* dc) {
-    __shared__ uint32_t s_cnt[4][WALK_BLOCK / 64];
+// The body of k_sss_step over queue entries first, first + stride, ... < n, for a block of BLOCK threads: the kernel runs
+// it grid-wide, the tail kernel (k_tail) on a wave's own paths.  c_* = the counters of the four queues it pushes to.
+template <bool CNT, int BLOCK>
+PT_DEV void sss_range(const SceneDev& S, const PathArrays& P, const uint32_t* q_walk, const uint32_t n, const uint32_t first, const uint32_t stride,
+                      uint32_t* q_walk_next, uint32_t* q_next, uint32_t* q_shadow, uint32_t* q_final,
+                      uint32_t* c_shadow, uint32_t* c_next, uint32_t* c_final, uint32_t* c_walk, const uint32_t max_bounces, ShadeCnt& sc) {
+    __shared__ uint32_t s_cnt[4][BLOCK / 64];
     __shared__ uint32_t s_base[4];
-    const uint32_t n = ctr->n_walk;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+    for (uint32_t base = first; base < n; base += stride) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
         bool alive = false, exited = false, push_sun = false, push_sky = false;
@@ -632,8 +631,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_sss_step(SceneDev S, PathArrays 
             __syncthreads();
             if (threadIdx.x < 4u) {
                 uint32_t total = 0;
-                for (uint32_t k = 0; k < WALK_BLOCK / 64; ++k) total += s_cnt[threadIdx.x][k];
-                uint32_t* counter = threadIdx.x == 0u ? &ctr->n_shadow : (threadIdx.x == 1u ? &ctr_next->n_active : (threadIdx.x == 2u ? &ctr->n_final : &ctr_next->n_walk));
+                for (uint32_t k = 0; k < BLOCK / 64; ++k) total += s_cnt[threadIdx.x][k];
+                uint32_t* counter = threadIdx.x == 0u ? c_shadow : (threadIdx.x == 1u ? c_next : (threadIdx.x == 2u ? c_final : c_walk));
                 s_base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
             }
             __syncthreads();
@@ -647,6 +646,14 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_sss_step(SceneDev S, PathArrays 
             __syncthreads();
         }
     }
+}
+template <bool CNT>
+__global__ __launch_bounds__(WALK_BLOCK) void k_sss_step(SceneDev S, PathArrays P, const uint32_t* q_walk, uint32_t* q_walk_next, uint32_t* q_next,
+                                                         uint32_t* q_shadow, uint32_t* q_final, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
+                                                         DevCounters* dc) {
+    ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
+    sss_range<CNT, WALK_BLOCK>(S, P, q_walk, ctr->n_walk, blockIdx.x * blockDim.x, gridDim.x * blockDim.x, q_walk_next, q_next, q_shadow, q_final,
+                               &ctr->n_shadow, &ctr_next->n_active, &ctr->n_final, &ctr_next->n_walk, max_bounces, sc);
     if (CNT) {
         wave_add(&dc->v[C_HITDATA], sc.hitdata);
         wave_add(&dc->v[C_SSS_STEPS], sc.sss_steps);
@@ -657,16 +664,14 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_sss_step(SceneDev S, PathArrays 
     }
 }
 
-template <bool CNT>
-__global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S, PathArrays P, const uint32_t* q, uint32_t* q_next, uint32_t* q_shadow,
-                                                       uint32_t* q_final, uint32_t* q_walk, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
-                                                       DevCounters* dc) {
-    __shared__ uint32_t s_cnt[4][SHADE_BLOCK / 64];
+// The body of k_shade over queue entries first, first + stride, ... < n, for a block of BLOCK threads (see sss_range).
+template <bool CNT, int BLOCK>
+PT_DEV void shade_range(const SceneDev& S, const PathArrays& P, const uint32_t* q, const uint32_t n, const uint32_t first, const uint32_t stride,
+                        uint32_t* q_next, uint32_t* q_shadow, uint32_t* q_final, uint32_t* q_walk,
+                        uint32_t* c_shadow, uint32_t* c_next, uint32_t* c_final, uint32_t* c_walk, const uint32_t max_bounces, ShadeCnt& sc) {
+    __shared__ uint32_t s_cnt[4][BLOCK / 64];
     __shared__ uint32_t s_base[4];
-    const uint32_t n = ctr->n_active;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+    for (uint32_t base = first; base < n; base += stride) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
         bool alive = false, push_sun = false, push_sky = false, walk = false;
@@ -929,8 +934,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
             __syncthreads();
             if (threadIdx.x < 4u) {
                 uint32_t total = 0;
-                for (uint32_t k = 0; k < SHADE_BLOCK / 64; ++k) total += s_cnt[threadIdx.x][k];
-                uint32_t* counter = threadIdx.x == 0u ? &ctr->n_shadow : (threadIdx.x == 1u ? &ctr_next->n_active : (threadIdx.x == 2u ? &ctr->n_final : &ctr_next->n_walk));
+                for (uint32_t k = 0; k < BLOCK / 64; ++k) total += s_cnt[threadIdx.x][k];
+                uint32_t* counter = threadIdx.x == 0u ? c_shadow : (threadIdx.x == 1u ? c_next : (threadIdx.x == 2u ? c_final : c_walk));
                 s_base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
             }
             __syncthreads();
@@ -944,6 +949,14 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
             __syncthreads();   // s_cnt / s_base are rewritten by the next iteration
         }
     }
+}
+template <bool CNT>
+__global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S, PathArrays P, const uint32_t* q, uint32_t* q_next, uint32_t* q_shadow,
+                                                       uint32_t* q_final, uint32_t* q_walk, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
+                                                       DevCounters* dc) {
+    ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
+    shade_range<CNT, SHADE_BLOCK>(S, P, q, ctr->n_active, blockIdx.x * blockDim.x, gridDim.x * blockDim.x, q_next, q_shadow, q_final, q_walk,
+                                  &ctr->n_shadow, &ctr_next->n_active, &ctr->n_final, &ctr_next->n_walk, max_bounces, sc);
     if (CNT) {
         wave_add(&dc->v[C_HITDATA], sc.hitdata);
         wave_add(&dc->v[C_MATERIAL], sc.material);
@@ -956,10 +969,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
 }
 
 // ---- finalize: finished paths -> clamp_radiance -> framebuffer ------------------------
-__global__ void k_finalize(PathArrays P, const uint32_t* q_final, const IterCtr* ctr, Target tg, DevCounters* dc, uint32_t counting) {
-    const uint32_t n = ctr->n_final;
+PT_DEV uint32_t finalize_range(const PathArrays& P, const uint32_t* q_final, const uint32_t n, const uint32_t first, const uint32_t stride, const Target& tg) {
     uint32_t written = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = first; i < n; i += stride) {
         const uint32_t p = q_final[i];
         const float4 ra4 = P.rad[p];
         V3 L = v3(ra4.x, ra4.y, ra4.z);
@@ -988,7 +1000,82 @@ __global__ void k_finalize(PathArrays P, const uint32_t* q_final, const IterCtr*
         }
         written++;
     }
+    return written;
+}
+__global__ void k_finalize(PathArrays P, const uint32_t* q_final, const IterCtr* ctr, Target tg, DevCounters* dc, uint32_t counting) {
+    const uint32_t written = finalize_range(P, q_final, ctr->n_final, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, tg);
     if (counting) wave_add(&dc->v[C_PIXEL_SAMPLES], written);
+}
+
+// ---- tail: the late iterations of a batch, wave by wave -----------------------------------------------
+// Once few paths are left, a grid-wide iteration lasts as long as the longest ray of the whole launch, four launches in
+// a row.  Here every wave takes an even slice of the active and walk queues and carries its own paths to their end:
+// extend -> shade -> walk step -> shadow -> finalize on queue stretches of its own, with no other wave to wait for, so a
+// phase lasts as long as the longest ray among the wave's own.  The phases are the kernels' own bodies (trace_queue,
+// shade_range, sss_range, finalize_range) and every path still draws from its own PCG stream: same bits
+// (test_tail_kernel_changes_nothing).
+#ifndef PT_TAIL_WAVES
+#define PT_TAIL_WAVES 3                             // k_shade's register budget
+#endif
+#ifndef PT_TAIL_PER_WAVE
+#define PT_TAIL_PER_WAVE 256
+#endif
+constexpr uint32_t TAIL_PER_WAVE = PT_TAIL_PER_WAVE;    // paths one wave can own
+constexpr int TAIL_GRID = 256 * 4 * PT_TAIL_WAVES;      // the waves that are resident together
+constexpr uint32_t TAIL_REGION = 7 * TAIL_PER_WAVE; // u32 of queue space per wave: active x2, walk x2, shadow (2 per path), final
+constexpr uint32_t PTX_DEV_ERR_TAIL = 0x100u;       // device error word: a wave was handed more than TAIL_PER_WAVE paths
+template <bool FAST, bool UNC>
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_TAIL_WAVES))) void k_tail(SceneDev S, PathArrays P, const uint32_t* q, const uint32_t* q_walk, const IterCtr* ctr,
+                                                     uint32_t* tail_q, uint32_t* left_alive, uint2* ovf, DevCounters* dc, uint32_t* err, Target tg,
+                                                     uint32_t max_bounces, uint32_t iters, uint32_t first_extend_done) {
+    __shared__ uint32_t t_c[8];     // 0 closest-hit cursor, 1 any-hit cursor, 2 shadow entries, 3 next active, 4 final, 5 next walk
+    const StackRef st = make_stack(ovf);
+    const uint32_t W = gridDim.x, w = blockIdx.x;
+    const uint32_t tot_a = ctr->n_active, tot_w = ctr->n_walk;
+    const uint32_t a_lo = (uint32_t)((unsigned long long)tot_a * w / W), a_hi = (uint32_t)((unsigned long long)tot_a * (w + 1u) / W);
+    const uint32_t w_lo = (uint32_t)((unsigned long long)tot_w * w / W), w_hi = (uint32_t)((unsigned long long)tot_w * (w + 1u) / W);
+    uint32_t nA = a_hi - a_lo, nW = w_hi - w_lo;
+    if (nA + nW > TAIL_PER_WAVE) {                  // the host sizes the grid from an upper bound of the live count
+        if (threadIdx.x == 0u) atomicOr(err, PTX_DEV_ERR_TAIL);
+        return;
+    }
+    uint32_t* const mine = tail_q + (size_t)w * TAIL_REGION;
+    uint32_t* const q_sh = mine + 4u * TAIL_PER_WAVE;
+    uint32_t* const q_fin = mine + 6u * TAIL_PER_WAVE;
+    const uint32_t* qa = q + a_lo;
+    const uint32_t* qw = q_walk + w_lo;
+    LaneCnt lc = {0, 0, 0, 0, 0, 0, 0, 0.0f, {0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, 0.0f};
+    ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t nrays = 0;
+    for (uint32_t it = 0; it < iters && (nA | nW) != 0u; ++it) {
+        uint32_t* const qa_next = mine + (it & 1u) * TAIL_PER_WAVE;
+        uint32_t* const qw_next = mine + (2u + (it & 1u)) * TAIL_PER_WAVE;
+        if (threadIdx.x < 8u) t_c[threadIdx.x] = 0u;
+        __syncthreads();
+        if (it != 0u || !first_extend_done) {     // the first closest-hit pass was an ordinary launch (it ran beside the any-hit launch before it)
+            ExtendSrc src{P, qa, nA, qw};
+            ExtendSink sink{P};
+            trace_queue<false, false, FAST, UNC, true>(S, st, &t_c[0], nA + nW, src, sink, lc, nrays, err, reinterpret_cast<unsigned long long*>(&dc->dbg[6]));
+        }
+        __syncthreads();    // one wave: no barrier, but the hit records the lanes wrote are read by other lanes below
+        shade_range<false, TRACE_BLOCK>(S, P, qa, nA, 0u, (uint32_t)TRACE_BLOCK, qa_next, q_sh, q_fin, qw_next, &t_c[2], &t_c[3], &t_c[4], &t_c[5], max_bounces, sc);
+        if (S.has_sss) sss_range<false, TRACE_BLOCK>(S, P, qw, nW, 0u, (uint32_t)TRACE_BLOCK, qw_next, qa_next, q_sh, q_fin, &t_c[2], &t_c[3], &t_c[4], &t_c[5], max_bounces, sc);
+        __syncthreads();
+        const uint32_t n_sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_c[2]), n_fin = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_c[4]);
+        nA = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_c[3]);
+        nW = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_c[5]);
+        if (n_sh) {
+            ShadowSrc src{S, P, q_sh};
+            ShadowSink sink{P};
+            trace_queue<true, false, false, false, true>(S, st, &t_c[1], n_sh, src, sink, lc, nrays, err);
+            __syncthreads();
+        }
+        (void)finalize_range(P, q_fin, n_fin, threadIdx.x, (uint32_t)TRACE_BLOCK, tg);
+        __syncthreads();
+        qa = qa_next;
+        qw = qw_next;
+    }
+    if ((nA | nW) != 0u && threadIdx.x == 0u) atomicAdd(left_alive, nA + nW);     // out of iterations (subsurface walks): run_paths refuses the frame
 }
 
 // ---- several passes in flight: add each pixel's samples in pass order (main.rs:131-137 / framebuffer.rs:44-50) ----
@@ -1268,6 +1355,14 @@ struct PtxContext {
     hipEvent_t ev_ext_in = nullptr, ev_ext_out = nullptr;     // ptx_order_after_stream / ptx_order_stream_after
     hipEvent_t ev_tail = nullptr;       // recorded once a frame's heavy iterations are enqueued (ptx_order_after_frame_tail)
     uint32_t tail_gate_iter = 3;        // PTX_TAIL_GATE_ITER
+    // k_tail (run_paths): the late iterations of a batch as one launch of independent waves
+    bool tail_kernel = true;            // PTX_TAIL_KERNEL=0: every iteration as its own launches
+    bool tail_poll = true;              // read the live count back to find the takeover point (off inside ptx_fb_render_passes_async, which must not wait)
+    uint32_t tail_first_poll = 1;       // PTX_TAIL_FIRST_POLL: first iteration whose live count is read back
+    hipEvent_t ev_poll = nullptr;
+    uint64_t tail_cap = ~0ull;          // PTX_TAIL_CAP: take over at this many live paths or fewer (at most what the waves can hold)
+    uint32_t tail_min_per_wave = 32;    // PTX_TAIL_MIN_PER_WAVE: fewer paths than this per wave are not worth another wave
+    uint32_t* tail_q = nullptr;         // TAIL_GRID x TAIL_REGION: the waves' own queue stretches
     bool overlap_shadow = true;
     std::string err;
 
@@ -1687,7 +1782,7 @@ static int32_t ensure_worklist(PtxContext* ctx, uint32_t w, uint32_t h) {
 }
 
 constexpr uint32_t SSS_POLL_EVERY = 8;
-enum { CLS_RAYGEN = 0, CLS_EXTEND, CLS_SHADE, CLS_SHADOW, CLS_ACCUM, CLS_OTHER, CLS_PACKET, CLS_WALK };
+enum { CLS_RAYGEN = 0, CLS_EXTEND, CLS_SHADE, CLS_SHADOW, CLS_ACCUM, CLS_OTHER, CLS_PACKET, CLS_WALK, CLS_TAIL };
 struct ScopedEvent {
     PtxContext* ctx; int idx = -1;
     ScopedEvent(PtxContext* c, int cls, hipStream_t on = nullptr) : ctx(c) {
@@ -1714,6 +1809,7 @@ static void drain_events(PtxContext* ctx) {
                 case CLS_SHADOW: ctx->timings.shadow_ms += ms; ctx->timings.shadow_launches++; break;
                 case CLS_ACCUM: ctx->timings.accumulate_ms += ms; break;
                 case CLS_WALK: ctx->timings.walk_ms += ms; ctx->timings.walk_launches++; break;
+                case CLS_TAIL: ctx->timings.tail_ms += ms; ctx->timings.tail_launches++; break;
                 default: ctx->timings.other_ms += ms; break;
             }
         }
@@ -1728,6 +1824,7 @@ static int32_t check_device_error(PtxContext* ctx) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->h_pinned[0] != 0) {
         HIPCHK(hipMemsetAsync(ctx->d_err, 0, 4, ctx->stream));
+        if (ctx->h_pinned[0] & PTX_DEV_ERR_TAIL) return fail(ctx, PTX_ERR_HIP, "internal: the tail kernel was launched with too few waves for the live paths");
         return fail(ctx, PTX_ERR_STACK_OVERFLOW, "a traversal needed more than the 144 stack entries a ray has on the device (the reference panics beyond 64 per BVH level)");
     }
     return PTX_OK;
@@ -1799,12 +1896,20 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
         PtxContext* c; bool armed = false;
         ~SideJoin() { if (armed && c->side_stream) (void)hipStreamSynchronize(c->side_stream); }
     } side_join{ctx};
+    // k_tail takes the batch over at the first iteration whose live paths fit its waves (that iteration's closest-hit
+    // pass is still an ordinary launch).  `live_ub` is what the host knows: the batch size, then the counts it reads back.
+    const uint64_t TAIL_CAP = std::min<uint64_t>(ctx->tail_cap, (uint64_t)TAIL_GRID * (TAIL_PER_WAVE - 2));      // - 2: a wave's two slices are rounded up
+    const bool tail = ctx->tail_kernel && ctx->tail_q != nullptr && !ctx->counting && !ctx->group_lanes;
+    uint64_t live_ub = n;
+    bool poll_pending = false;
     for (uint32_t it = 0; it < iter_cap; ++it) {
         uint32_t* qa = ctx->q[it & 1];
         uint32_t* qb = ctx->q[(it + 1) & 1];
         uint32_t* qwa = ctx->q_walk[it & 1];          // subsurface walks in flight: their step rays are traced with qa
         uint32_t* qwb = ctx->q_walk[(it + 1) & 1];
         IterCtr* c = ctx->ctrs + it;
+        const bool poll = poll_pending;     // this iteration's live count is on its way to the host (enqueued behind k_shade(it - 1), below)
+        poll_pending = false;
         {
             // primary rays of neighbouring queue entries are coherent (a pixel's samples, or an 8x8 tile): packets
             const bool packets = it == 0 && coherent && ctx->packet_primary && !ctx->counting;
@@ -1833,6 +1938,37 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
                 else hipLaunchKernelGGL((k_extend<false, false>), dim3(trace_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->ovf, ctx->d_counters, ctx->d_err);
             }
         }
+        if (tail) {
+            if (poll) {
+                HIPCHK(hipEventSynchronize(ctx->ev_poll));
+                live_ub = (uint64_t)ctx->h_pinned[20] + ctx->h_pinned[23];
+                if (live_ub == 0) { drained = true; break; }        // (the launch above found an empty queue)
+            }
+            if (live_ub <= TAIL_CAP) {
+                // as few paths per wave as the resident waves allow (a wave's phase lasts as long as its longest ray)
+                const uint64_t per_wave = std::min<uint64_t>(TAIL_PER_WAVE - 2, std::max<uint64_t>(ctx->tail_min_per_wave, (live_ub + TAIL_GRID - 1) / TAIL_GRID));
+                const int tg_grid = (int)std::max<uint64_t>(1, (live_ub + per_wave - 1) / per_wave);
+                uint32_t* left = &ctx->ctrs[CTR_TAIL].n_active;
+                HIPCHK(hipMemsetAsync(left, 0, 4, ctx->stream));
+                // iteration it - 1's any-hit launch and k_finalize (side stream) read and zero the pending terms k_tail's
+                // shading adds; they ran beside the closest-hit launch above
+                if (side_pending) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0)); side_pending = false; }
+                {
+                    ScopedEvent ev(ctx, CLS_TAIL);
+                    const bool fast = ctx->S.fast_on != 0u;
+                    const uint32_t iters = iter_cap - it;
+                    if (fast && ctx->n_uncertified) hipLaunchKernelGGL((k_tail<true, true>), dim3(tg_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->tail_q, left, ctx->ovf, ctx->d_counters, ctx->d_err, tg, max_bounces, iters, 1u);
+                    else if (fast) hipLaunchKernelGGL((k_tail<true, false>), dim3(tg_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->tail_q, left, ctx->ovf, ctx->d_counters, ctx->d_err, tg, max_bounces, iters, 1u);
+                    else hipLaunchKernelGGL((k_tail<false, false>), dim3(tg_grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qwa, c, ctx->tail_q, left, ctx->ovf, ctx->d_counters, ctx->d_err, tg, max_bounces, iters, 1u);
+                }
+                if (sss) {
+                    HIPCHK(hipMemcpyAsync(ctx->h_pinned + 24, left, 4, hipMemcpyDeviceToHost, ctx->stream));
+                    HIPCHK(hipStreamSynchronize(ctx->stream));
+                    drained = ctx->h_pinned[24] == 0;
+                }
+                break;
+            }
+        }
         if (it == ctx->tail_gate_iter) { HIPCHK(hipEventRecord(ctx->ev_tail, ctx->stream)); tail_recorded = true; }
         // iteration it - 1's any-hit launch (side stream) zeroes the pending terms this k_shade adds, and reads the shadow
         // and final queues this k_shade overwrites
@@ -1859,6 +1995,14 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
             side_join.armed = true;
             HIPCHK(hipEventRecord(ctx->ev_main, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ss, ctx->ev_main, 0));
+        }
+        if (tail && live_ub > TAIL_CAP && ctx->tail_poll && it + 1 >= ctx->tail_first_poll && it + 1 < iter_cap) {
+            // The next iteration's live count goes to the host from the side stream: the next closest-hit launch (main
+            // stream) is then the first kernel ready when k_shade ends, as without the copy (the any-hit launch taking the
+            // wave slots first costs 1 ms per heavy iteration), and the host's wait ends while that launch has the GPU busy.
+            HIPCHK(hipMemcpyAsync(ctx->h_pinned + 20, c + 1, 16, hipMemcpyDeviceToHost, ss));      // n_active .. n_walk
+            HIPCHK(hipEventRecord(ctx->ev_poll, ss));
+            poll_pending = true;
         }
         {
             ScopedEvent ev(ctx, CLS_SHADOW, ss);
@@ -1965,7 +2109,13 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
         HIPCHK(hipMalloc((void**)&c->ovf_side, sizeof(uint2) * (size_t)std::max(MAX_TRACE_GRID, PACKET_GRID) * TRACE_BLOCK * OVF_STACK));
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_poll, hipEventDisableTiming));
     if (const char* e = std::getenv("PTX_TAIL_GATE_ITER")) c->tail_gate_iter = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("PTX_TAIL_KERNEL")) c->tail_kernel = std::strtoul(e, nullptr, 10) != 0;
+    if (const char* e = std::getenv("PTX_TAIL_CAP")) c->tail_cap = std::strtoull(e, nullptr, 10);
+    if (const char* e = std::getenv("PTX_TAIL_FIRST_POLL")) c->tail_first_poll = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("PTX_TAIL_MIN_PER_WAVE")) c->tail_min_per_wave = (uint32_t)std::max(1ul, std::min<unsigned long>(std::strtoul(e, nullptr, 10), TAIL_PER_WAVE - 2));
+    if (c->tail_kernel) HIPCHK(hipMalloc((void**)&c->tail_q, sizeof(uint32_t) * (size_t)TAIL_GRID * TAIL_REGION));
     HIPCHK(hipEventCreateWithFlags(&c->ev_ext_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_ext_out, hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&c->ctrs, sizeof(IterCtr) * CTR_BLOCKS));
@@ -1995,9 +2145,11 @@ int32_t ptx_destroy(PtxContext* ctx) {
     if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
     if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
     if (ctx->ev_tail) (void)hipEventDestroy(ctx->ev_tail);
+    if (ctx->ev_poll) (void)hipEventDestroy(ctx->ev_poll);
     if (ctx->ev_ext_in) (void)hipEventDestroy(ctx->ev_ext_in);
     if (ctx->ev_ext_out) (void)hipEventDestroy(ctx->ev_ext_out);
     if (ctx->ovf_side) (void)hipFree(ctx->ovf_side);
+    if (ctx->tail_q) (void)hipFree(ctx->tail_q);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PTX_OK;
@@ -2449,7 +2601,14 @@ int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t co
     return fb_render_passes(ctx, first_sample, count, max_bounces, true);
 }
 int32_t ptx_fb_render_passes_async(PtxContext* ctx, uint32_t first_sample, uint32_t count, uint32_t max_bounces) {
-    return fb_render_passes(ctx, first_sample, count, max_bounces, false);
+    if (!ctx) return fail(nullptr, PTX_ERR_INVALID, "null context");
+    // no host wait: k_tail takes over only where the batch size alone says the live paths fit (scenes with subsurface
+    // materials still wait, as they always did: their iteration count is data dependent)
+    const bool poll = ctx->tail_poll;
+    ctx->tail_poll = false;
+    const int32_t st = fb_render_passes(ctx, first_sample, count, max_bounces, false);
+    ctx->tail_poll = poll;
+    return st;
 }
 
 int32_t ptx_fb_adaptive_pass(PtxContext* ctx, const PtxAdaptiveConfig* cfg, uint32_t max_bounces, uint64_t* out_rendered) {

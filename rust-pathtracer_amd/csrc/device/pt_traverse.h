@@ -574,13 +574,14 @@ struct Traverser {
 // call for an entry is its result); `Sink::done(k, found)` ends the entry.
 // `work` is the queue's shared cursor, `n` its length.
 // FAST (closest-hit only): see above.
-template <bool ANY, bool CNT, bool FAST = false, bool UNC = false, class Src, class Sink>
+// LOCAL: the queue and its cursor belong to this wave alone (k_tail): every wave of the grid has entries of its own.
+template <bool ANY, bool CNT, bool FAST = false, bool UNC = false, bool LOCAL = false, class Src, class Sink>
 PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, const uint32_t n, const Src& src, const Sink& sink,
                         LaneCnt& lc, uint32_t& nrays, uint32_t* err,       // err: the device error word (set on a stack overflow)
                         unsigned long long* again_count = nullptr) {            // FAST: statistics, rays traced a second time
     // a short queue cannot feed every wave: the surplus ones leave without touching the cursors (6144 waves bumping
     // a few addresses made an empty launch cost 70 us)
-    if ((unsigned long long)blockIdx.x * 16ull >= (unsigned long long)n + 128ull) return;
+    if (!LOCAL && (unsigned long long)blockIdx.x * 16ull >= (unsigned long long)n + 128ull) return;
     Traverser<ANY, CNT, FAST, UNC> tv;
     tv.act = ACT_IDLE;
     tv.exact = false; tv.in_mesh = false; tv.found = false; tv.amb_w = false; tv.amb_l = false; tv.slow = false;
@@ -596,7 +597,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
     const uint32_t lane = threadIdx.x & 63u;
     // short queues keep one cursor: with few entries per wave the extra cursor traffic at the end of every segment
     // costs more than the L2 affinity gains (Cornell 640x360: 7.8 ms per frame with one cursor, 9.3 with eight)
-    const uint32_t seg_shift = n >= SEGMENT_MIN_QUEUE ? QUEUE_SEGMENT_SHIFT : 0u, nseg = 1u << seg_shift;
+    const uint32_t seg_shift = !LOCAL && n >= SEGMENT_MIN_QUEUE ? QUEUE_SEGMENT_SHIFT : 0u, nseg = 1u << seg_shift;
     const uint32_t seg_size = (n + nseg - 1u) >> seg_shift;   // n < 2^31
     uint32_t seg = blockIdx.x & (nseg - 1u), seg_left = nseg;   // wave-uniform
     for (;;) {

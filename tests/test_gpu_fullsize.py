@@ -338,6 +338,7 @@ def test_side_stream_overlap_changes_nothing(pkg, oracle_det, full_scenes, monke
     w, h, spp, bounces = 192, 108, 6, 16
     cam = sc.default_camera(w / h)
     frames = []
+    monkeypatch.setenv("PTX_TAIL_CAP", "3000")      # k_tail (which has no side stream) only takes the last 3000 paths of a batch
     for overlap in ("1", "0"):
         monkeypatch.setenv("PTX_OVERLAP_SHADOW", overlap)
         monkeypatch.setenv("PTX_PATHS_IN_FLIGHT", str(w * h * 4))       # 6 passes = a batch of 4 + a batch of 2
@@ -351,6 +352,47 @@ def test_side_stream_overlap_changes_nothing(pkg, oracle_det, full_scenes, monke
     for a, b in zip(frames[0], frames[1]):
         assert np.array_equal(bits(a), bits(b))
     assert np.array_equal(bits(frames[0][3]), bits(oracle_det.scene(sc).render_pass(cam, w, h, 2, bounces)))
+
+
+def test_tail_kernel_changes_nothing(pkg, oracle_det, full_scenes, monkeypatch):
+    """By default the late iterations of a batch run as one k_tail launch (every wave carries its own paths through
+    extend -> shade -> walk step -> shadow -> finalize until they end; run_paths).  The frame must be the
+    launch-per-iteration frame bit for bit: small batches (k_tail from the first shading on, sized from the batch alone), large
+    ones (the takeover point found by reading the live count back), few and many paths per wave, plain passes, adaptive
+    passes, the subsurface walk queue — and equal the oracle's."""
+    sc = full_scenes("bistro_like")           # flags 3: sky + sun + SSS materials
+    bounces = 16
+    results = {}
+    for label, env, (w, h, spp) in (("off", {"PTX_TAIL_KERNEL": "0"}, (192, 108, 6)),
+                                   ("on", {}, (192, 108, 6)),
+                                   ("on/8 per wave", {"PTX_TAIL_MIN_PER_WAVE": "8"}, (192, 108, 6)),
+                                   ("on/254 per wave", {"PTX_TAIL_MIN_PER_WAVE": "254"}, (192, 108, 6)),
+                                   ("on/late", {"PTX_TAIL_CAP": "3000"}, (192, 108, 6)),
+                                   ("on/late, one stream", {"PTX_TAIL_CAP": "3000", "PTX_OVERLAP_SHADOW": "0"}, (192, 108, 6)),
+                                   ("off/large", {"PTX_TAIL_KERNEL": "0"}, (640, 360, 4)),
+                                   ("on/large", {"PTX_TAIL_FIRST_POLL": "2"}, (640, 360, 4))):
+        for k in ("PTX_TAIL_KERNEL", "PTX_TAIL_MIN_PER_WAVE", "PTX_TAIL_FIRST_POLL", "PTX_TAIL_CAP", "PTX_OVERLAP_SHADOW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("PTX_PATHS_IN_FLIGHT", str(w * h * 4))       # 6 passes = a batch of 4 + a batch of 2
+        lp = pkg.HipRenderLoop(0)
+        lp.set_profiling(True)
+        cam = sc.default_camera(w / h)
+        fb = pkg.DeviceFramebuffer(lp, w, h, adaptive=True)
+        fb.render_passes(sc, cam, pkg.PathTracer(bounces), 0, spp)
+        lp.render_adaptive_passes(sc, cam, pkg.PathTracer(bounces), fb, pkg.AdaptiveSamplingConfig(4, 0.0005), 3)
+        one = lp.render_pass(sc, cam, pkg.PathTracer(bounces), w, h, 2)
+        t = lp.timings()
+        assert (t["tail_launches"] > 0) == label.startswith("on"), (label, t)
+        print(f"\n[{label}] {w}x{h}: tail launches {t['tail_launches']}, {t['tail_ms']:.2f} ms; extend launches {t['extend_launches']}, {t['extend_ms']:.2f} ms")
+        results[label] = fb.read() + (one,)
+    for label in ("on", "on/8 per wave", "on/254 per wave", "on/late", "on/late, one stream"):
+        for a, b in zip(results["off"], results[label]):
+            assert np.array_equal(bits(a), bits(b)), label
+    for a, b in zip(results["off/large"], results["on/large"]):
+        assert np.array_equal(bits(a), bits(b))
+    assert np.array_equal(bits(results["on"][3]), bits(oracle_det.scene(sc).render_pass(sc.default_camera(192 / 108), 192, 108, 2, bounces)))
 
 
 def test_nearest_first_equals_reference_order_on_the_full_scenes(pkg, loop, oracle_det, full_scenes, monkeypatch):

@@ -21,8 +21,8 @@ for line in r.stderr.splitlines():
     if m and cur and "rocprim" not in cur:
         rows.setdefault(cur, {})[m.group(1).split(" ")[0]] = int(m.group(2))
 for name, v in rows.items():
-    m = re.search(r"\d+(k_[a-z_]+)(?:I((?:Lb\d)+)E)?", name)
-    short = (m.group(1) + ("<" + ",".join(m.group(2)[2::3]) + ">" if m.group(2) else "")) if m else name[:40]
+    m = re.search(r"\d+(k_[a-z_]+)(?:I((?:L[bij]\d+E)+)E)?", name)
+    short = (m.group(1) + ("<" + ",".join(re.findall(r"L[bij](\d+)E", m.group(2))) + ">" if m.group(2) else "")) if m else name[:40]
     print(f"{short:42s} VGPR {v.get('VGPRs', 0):4d} AGPR {v.get('AGPRs', 0):3d} SGPR {v.get('TotalSGPRs', 0):4d} scratch {v.get('ScratchSize', 0):5d} "
           f"LDS {v.get('LDS', 0):6d} occ {v.get('Occupancy', 0)}")
 if r.returncode != 0:
