@@ -315,7 +315,9 @@ int32_t ptx_fb_render_passes(PtxContext* ctx, uint32_t first_sample, uint32_t co
  * ptx_fb_read*, ptx_fb_tonemap_srgb8) instead of by this one.  Lets a host keep several frames in flight — e.g. two
  * contexts rendering alternate frames, so that the latency-bound last iterations of one frame share the GPU with the
  * first iterations of the next (bench.py --frames-in-flight).  Scenes with subsurface materials still poll the device
- * every few iterations (their iteration count is data dependent). */
+ * every few iterations (their iteration count is data dependent).  The synchronous calls read a 16-byte live count per
+ * iteration to hand the last paths of a batch to the tail kernel (PTX_TAIL_KERNEL); this call does not, and uses the tail
+ * kernel only for batches small enough to fit it from the start. */
 int32_t ptx_fb_render_passes_async(PtxContext* ctx, uint32_t first_sample, uint32_t count, uint32_t max_bounces);
 /* Two contexts on one GPU rendering alternate frames: everything `ctx` enqueues from now on starts after `other`'s most
  * recent ptx_fb_render_passes* call has got past its heavy iterations (the launches of its first three path-tracing

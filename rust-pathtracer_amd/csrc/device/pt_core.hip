@@ -1898,7 +1898,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
     } side_join{ctx};
     // k_tail takes the batch over at the first iteration whose live paths fit its waves (that iteration's closest-hit
     // pass is still an ordinary launch).  `live_ub` is what the host knows: the batch size, then the counts it reads back.
-    const uint64_t TAIL_CAP = std::min<uint64_t>(ctx->tail_cap, (uint64_t)TAIL_GRID * (TAIL_PER_WAVE - 2));      // - 2: a wave's two slices are rounded up
+    const uint64_t tail_cap = std::min<uint64_t>(ctx->tail_cap, (uint64_t)TAIL_GRID * (TAIL_PER_WAVE - 2));      // - 2: a wave's two slices are rounded up
     const bool tail = ctx->tail_kernel && ctx->tail_q != nullptr && !ctx->counting && !ctx->group_lanes;
     uint64_t live_ub = n;
     bool poll_pending = false;
@@ -1944,7 +1944,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
                 live_ub = (uint64_t)ctx->h_pinned[20] + ctx->h_pinned[23];
                 if (live_ub == 0) { drained = true; break; }        // (the launch above found an empty queue)
             }
-            if (live_ub <= TAIL_CAP) {
+            if (live_ub <= tail_cap) {
                 // as few paths per wave as the resident waves allow (a wave's phase lasts as long as its longest ray)
                 const uint64_t per_wave = std::min<uint64_t>(TAIL_PER_WAVE - 2, std::max<uint64_t>(ctx->tail_min_per_wave, (live_ub + TAIL_GRID - 1) / TAIL_GRID));
                 const int tg_grid = (int)std::max<uint64_t>(1, (live_ub + per_wave - 1) / per_wave);
@@ -1996,7 +1996,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
             HIPCHK(hipEventRecord(ctx->ev_main, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ss, ctx->ev_main, 0));
         }
-        if (tail && live_ub > TAIL_CAP && ctx->tail_poll && it + 1 >= ctx->tail_first_poll && it + 1 < iter_cap) {
+        if (tail && live_ub > tail_cap && ctx->tail_poll && it + 1 >= ctx->tail_first_poll && it + 1 < iter_cap) {
             // The next iteration's live count goes to the host from the side stream: the next closest-hit launch (main
             // stream) is then the first kernel ready when k_shade ends, as without the copy (the any-hit launch taking the
             // wave slots first costs 1 ms per heavy iteration), and the host's wait ends while that launch has the GPU busy.
