@@ -648,7 +648,7 @@ PT_DEV void sss_range(const SceneDev& S, const PathArrays& P, const uint32_t* q_
     }
 }
 template <bool CNT>
-__global__ __launch_bounds__(WALK_BLOCK) void k_sss_step(SceneDev S, PathArrays P, const uint32_t* q_walk, uint32_t* q_walk_next, uint32_t* q_next,
+__global__ __launch_bounds__(WALK_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_sss_step(SceneDev S, PathArrays P, const uint32_t* q_walk, uint32_t* q_walk_next, uint32_t* q_next,
                                                          uint32_t* q_shadow, uint32_t* q_final, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
                                                          DevCounters* dc) {
     ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
@@ -665,7 +665,9 @@ __global__ __launch_bounds__(WALK_BLOCK) void k_sss_step(SceneDev S, PathArrays 
 }
 
 // The body of k_shade over queue entries first, first + stride, ... < n, for a block of BLOCK threads (see sss_range).
-template <bool CNT, int BLOCK>
+// SPEC ("Sky search ahead"): the two CDF searches of sample_sky_light start ahead of the hit-data and
+// material gathers, on the numbers the sky sample will draw unless the material draws first (transmission, subsurface).
+template <bool CNT, int BLOCK, bool SPEC = false>
 PT_DEV void shade_range(const SceneDev& S, const PathArrays& P, const uint32_t* q, const uint32_t n, const uint32_t first, const uint32_t stride,
                         uint32_t* q_next, uint32_t* q_shadow, uint32_t* q_final, uint32_t* q_walk,
                         uint32_t* c_shadow, uint32_t* c_next, uint32_t* c_final, uint32_t* c_walk, const uint32_t max_bounces, ShadeCnt& sc) {
@@ -728,7 +730,23 @@ PT_DEV void shade_range(const SceneDev& S, const PathArrays& P, const uint32_t* 
                     }
                     alive = false;
                 } else {
-                    const HitData hit = compute_hit_data(S, h_inst, P.hit_tri[p], hi4.x, hi4.y, hi4.z);
+                    // The sky-light sample's two numbers are this vertex's first two draws unless the material draws
+                    // first; its six dependent table reads do not depend on the hit, so they are issued here, beside the
+                    // hit-data -> material -> texel chain instead of behind it.  A vertex whose material did draw first
+                    // (drew) searches again with its own numbers below.
+                    SkyUV suv = {0.0f, 0.0f};
+                    bool drew = false;
+                    HitData hit;
+                    if (SPEC) {
+                        Rng r2 = rng;
+                        const float a1 = r2.next();
+                        const float a2 = r2.next();
+                        float4 i0, i1, i2, qa, qb, qc, qd, qe;
+                        suv = gather_hit_and_sky(S, h_inst, &P.hit_tri[p], a1, a2, i0, i1, i2, qa, qb, qc, qd, qe);
+                        hit = hit_data_from(i0, i1, i2, qa, qb, qc, qd, qe, hi4.x, hi4.y, hi4.z);
+                    } else {
+                        hit = compute_hit_data(S, h_inst, P.hit_tri[p], hi4.x, hi4.y, hi4.z);
+                    }
                     if (CNT) { sc.hitdata++; sc.material++; }
                     const PtxMaterial& material = S.materials[hit.material_id];
                     const SampledMaterial mat = sample_material(S, material, hit, sc);
@@ -752,6 +770,7 @@ PT_DEV void shade_range(const SceneDev& S, const PathArrays& P, const uint32_t* 
                     const float transmission = material.transmission;
                     bool handled = false;
 
+                    if (SPEC && transmission > 0.0f) drew = true;
                     if (transmission > 0.0f && rng.next() < transmission) {
                         // sample_transmission (pathtracer.rs:328-348)
                         const float ior = material.ior;
@@ -772,6 +791,7 @@ PT_DEV void shade_range(const SceneDev& S, const PathArrays& P, const uint32_t* 
                     }
                     if (!handled) {
                         const float sss_prob = (material.subsurface > 0.0f && front_face) ? material.subsurface : 0.0f;
+                        if (SPEC && sss_prob > 0.0f) drew = true;
                         if (sss_prob > 0.0f && rng.next() < sss_prob) {
                             handled = true;
                             T = T / sss_prob;
@@ -825,7 +845,9 @@ PT_DEV void shade_range(const SceneDev& S, const PathArrays& P, const uint32_t* 
                         {
                             const float u1 = rng.next();
                             const float u2 = rng.next();
-                            const SkySample ss = sky_sample_direction<!CNT>(S, u1, u2, sc);
+                            SkySample ss;
+                            if (SPEC) ss = sky_sample_at(S, drew ? sky_search_uv<true>(S, u1, u2, sc) : suv, sc);
+                            else ss = sky_sample_direction<!CNT>(S, u1, u2, sc);
                             const V3 l = ss.direction;
                             const float n_dot_l = dot(nrm, l);
                             if (!(n_dot_l <= 0.0f || ss.pdf <= 0.0f)) {
@@ -950,12 +972,12 @@ PT_DEV void shade_range(const SceneDev& S, const PathArrays& P, const uint32_t* 
         }
     }
 }
-template <bool CNT>
+template <bool CNT, bool SPEC = false>
 __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S, PathArrays P, const uint32_t* q, uint32_t* q_next, uint32_t* q_shadow,
                                                        uint32_t* q_final, uint32_t* q_walk, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
                                                        DevCounters* dc) {
     ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
-    shade_range<CNT, SHADE_BLOCK>(S, P, q, ctr->n_active, blockIdx.x * blockDim.x, gridDim.x * blockDim.x, q_next, q_shadow, q_final, q_walk,
+    shade_range<CNT, SHADE_BLOCK, SPEC>(S, P, q, ctr->n_active, blockIdx.x * blockDim.x, gridDim.x * blockDim.x, q_next, q_shadow, q_final, q_walk,
                                   &ctr->n_shadow, &ctr_next->n_active, &ctr->n_final, &ctr_next->n_walk, max_bounces, sc);
     if (CNT) {
         wave_add(&dc->v[C_HITDATA], sc.hitdata);
@@ -1364,6 +1386,8 @@ struct PtxContext {
     uint32_t tail_min_per_wave = 32;    // PTX_TAIL_MIN_PER_WAVE: fewer paths than this per wave are not worth another wave
     uint32_t* tail_q = nullptr;         // TAIL_GRID x TAIL_REGION: the waves' own queue stretches
     bool overlap_shadow = true;
+    bool sky_ahead_env = true;          // PTX_SKY_AHEAD=0: k_shade searches the sky tables where the reference does
+    bool sky_ahead = false;             // this scene's sky has the three-level tables k_shade<false, true> reads (set by ptx_upload_scene)
     std::string err;
 
     bool has_scene = false, has_camera = false;
@@ -1976,6 +2000,7 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
         {
             ScopedEvent ev(ctx, CLS_SHADE);
             if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, dim3(final_grid), dim3(SHADE_BLOCK)   /* counted: few blocks, each ends with 7 counter atomics per wave */, 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, qwb, c, c + 1, max_bounces, ctx->d_counters);
+            else if (ctx->sky_ahead) hipLaunchKernelGGL((k_shade<false, true>), dim3(shade_grid), dim3(SHADE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, qwb, c, c + 1, max_bounces, ctx->d_counters);
             else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(SHADE_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qa, qb, ctx->q_shadow, ctx->q_final, qwb, c, c + 1, max_bounces, ctx->d_counters);
         }
         if (sss && it > 0) {
@@ -2102,6 +2127,7 @@ int32_t ptx_create(int32_t device_index, PtxContext** out_ctx) {
     }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char* e = std::getenv("PTX_OVERLAP_SHADOW")) c->overlap_shadow = std::strtoul(e, nullptr, 10) != 0;
+    if (const char* e = std::getenv("PTX_SKY_AHEAD")) c->sky_ahead_env = std::strtoul(e, nullptr, 10) != 0;
     if (c->overlap_shadow) {
         HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
@@ -2310,6 +2336,7 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
         for (size_t r = 0; r < S.sky_h && monotone; ++r)
             for (uint32_t i = 0; i < S.sky_w && monotone; ++i) monotone = conditional[r * (S.sky_w + 1) + i] <= conditional[r * (S.sky_w + 1) + i + 1];
         std::vector<float> search;
+        bool sky_tables3 = false;
         const float inf = __builtin_inff();
         auto level_sizes = [](uint32_t n_real, uint32_t* sizes) {   // padded sizes per level; returns the level count (0 = too large)
             uint32_t levels = 0, n = n_real;
@@ -2317,7 +2344,7 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
                 if (levels == 4) return 0u;
                 const uint32_t padded = (n + 1u + 15u) / 16u * 16u;
                 sizes[levels++] = padded;
-                if (padded == 16u) return levels;
+                if (padded == 16u && levels >= 3u) return levels;      // at least three levels (a level above the last real one holds +inf only: its count is 0), so that k_shade's straight-line search serves every sky up to 4095 entries a side
                 n = padded / 16u;
             }
         };
@@ -2344,10 +2371,12 @@ int32_t ptx_upload_scene(PtxContext* ctx, const PtxSceneDesc* sc) {
                 build(marginal.data(), S.sky_h, sm, lm, off_m, 0, zero);
                 for (size_t r = 0; r < S.sky_h; ++r) build(&conditional[r * (S.sky_w + 1)], S.sky_w, scs, lc, off_c, r, scs);
                 S.cdf_levels_m = lm; S.cdf_levels_c = lc;
+                sky_tables3 = lm == 3u && lc == 3u;
                 for (uint32_t l = 0; l < 4; ++l) { S.cdf_off_m[l] = (uint32_t)off_m[l]; S.cdf_off_c[l] = (uint32_t)off_c[l]; S.cdf_stride_c[l] = scs[l]; }
             }
         }
         HIPCHK(dev_upload(pool, &S.sky_search, search));
+        ctx->sky_ahead = ctx->sky_ahead_env && sky_tables3;
     }
     HIPCHK(dev_upload(pool, &S.bn_pixel, bn_pixel)); HIPCHK(dev_upload(pool, &S.bn_lens, bn_lens));
     S.bn_size = sc->blue_noise_pixel.size;

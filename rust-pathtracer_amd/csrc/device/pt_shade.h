@@ -120,21 +120,11 @@ PT_DEV uint32_t cdf_count16(const float* tab, const uint32_t* off, const uint32_
     return g;
 }
 struct SkySample { V3 direction, radiance; float pdf; };
+// sample_direction (sky/texture.rs:149-188) in two halves: the CDF searches (u1, u2) -> (u, v), and everything behind them.
+struct SkyUV { float u, v; };
 // FAST: use the 16-ary tables when the scene has them (the counting kernels keep the reference's probe sequence)
 template <bool FAST>
-PT_DEV SkySample sky_sample_direction(const SceneDev& S, float u1, float u2, ShadeCnt& sc) {
-    SkySample r;
-    if (S.sky_total_weight <= 0.0f) {
-        const float phi = u1 * 2.0f * PT_PI;
-        const float cos_theta = 1.0f - 2.0f * u2;
-        const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-        float sp, cp;
-        d_sincosf(phi, &sp, &cp);
-        r.direction = v3(sin_theta * cp, cos_theta, sin_theta * sp);
-        r.radiance = sky_sample(S, r.direction, sc);
-        r.pdf = 1.0f / (4.0f * PT_PI);
-        return r;
-    }
+PT_DEV SkyUV sky_search_uv(const SceneDev& S, float u1, float u2, ShadeCnt& sc) {
     const uint32_t W = S.sky_w, H = S.sky_h;
     const uint32_t zero_stride[4] = {0u, 0u, 0u, 0u};
     uint32_t y;
@@ -142,24 +132,99 @@ PT_DEV SkySample sky_sample_direction(const SceneDev& S, float u1, float u2, Sha
     else y = cdf_search(S.sky_marginal, H + 1, u1, sc.cdf_probes);
     const float v_lo = S.sky_marginal[y], v_hi = S.sky_marginal[y + 1];
     const float dv = (u1 - v_lo) / (v_hi - v_lo + 1e-10f);
-    const float v = ((float)y + dv) / (float)H;
+    SkyUV r;
+    r.v = ((float)y + dv) / (float)H;
     const float* row_cdf = S.sky_conditional + (size_t)y * (W + 1);
     uint32_t x;
     if (FAST && S.cdf_levels_c) { const uint32_t lo = cdf_count16(S.sky_search, S.cdf_off_c, S.cdf_stride_c, y, S.cdf_levels_c, u2); x = lo == 0u ? 0u : lo - 1u; }
     else x = cdf_search(row_cdf, W + 1, u2, sc.cdf_probes);
     const float u_lo = row_cdf[x], u_hi = row_cdf[x + 1];
     const float du = (u2 - u_lo) / (u_hi - u_lo + 1e-10f);
-    const float u = ((float)x + du) / (float)W;
+    r.u = ((float)x + du) / (float)W;
+    return r;
+}
+// The same searches as straight-line code for scenes whose tables have exactly three levels each (the upload pads
+// shallower ones): no loop, no branch, so that the compiler can run this chain of six dependent reads BESIDE another
+// chain of the same basic block (k_shade starts it ahead of the hit-data and material gathers: "Sky search ahead").
+PT_DEV void load16f(const float* q, float4& a, float4& b, float4& c, float4& d) {
+    const float4* p = reinterpret_cast<const float4*>(q);
+    a = p[0]; b = p[1]; c = p[2]; d = p[3];
+}
+PT_DEV uint32_t count16f(const float4 a, const float4 b, const float4 c, const float4 d, float u) {
+    return (uint32_t)(a.x <= u) + (uint32_t)(a.y <= u) + (uint32_t)(a.z <= u) + (uint32_t)(a.w <= u) +
+           (uint32_t)(b.x <= u) + (uint32_t)(b.y <= u) + (uint32_t)(b.z <= u) + (uint32_t)(b.w <= u) +
+           (uint32_t)(c.x <= u) + (uint32_t)(c.y <= u) + (uint32_t)(c.z <= u) + (uint32_t)(c.w <= u) +
+           (uint32_t)(d.x <= u) + (uint32_t)(d.y <= u) + (uint32_t)(d.z <= u) + (uint32_t)(d.w <= u);
+}
+// compute_hit_data's two gathers (InstShade -> ShadeTri) and the sky searches' reads, issued as ONE interleaved sequence:
+// a load is written where it can be issued, its use where the other chain's next load has been issued, so that each wait
+// of one chain has a read of the other in flight beside it (loads return in order; the waits the compiler inserts count
+// the younger ones that may stay outstanding).
+PT_DEV SkyUV gather_hit_and_sky(const SceneDev& S, uint32_t inst, const uint32_t* hit_tri_slot, float u1, float u2,
+                                float4& i0, float4& i1, float4& i2, float4& qa, float4& qb, float4& qc, float4& qd, float4& qe) {
+    const uint32_t W = S.sky_w, H = S.sky_h;
+    const float* t = S.sky_search;
+    float4 a, b, c, d;
+    const float4* isp = reinterpret_cast<const float4*>(&S.inst_shade[inst]);
+    i0 = isp[0]; i1 = isp[1]; i2 = isp[2];                                   // hit 1
+    const uint32_t tri_idx = *hit_tri_slot;
+    load16f(t + S.cdf_off_m[2], a, b, c, d);                                 // sky 1
+    __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the hit chain's loads to their first use, behind the whole search)
+    uint32_t g = count16f(a, b, c, d, u1);
+    load16f(t + S.cdf_off_m[1] + 16u * g, a, b, c, d);                       // sky 2
+    const float4* q = reinterpret_cast<const float4*>(&S.shade_tris[(size_t)__float_as_uint(i2.z) + tri_idx]);
+    qa = q[0]; qb = q[1]; qc = q[2]; qd = q[3]; qe = q[4];                   // hit 2
+    __builtin_amdgcn_sched_barrier(0);
+    g = 16u * g + count16f(a, b, c, d, u1);
+    load16f(t + S.cdf_off_m[0] + 16u * g, a, b, c, d);                       // sky 3
+    g = 16u * g + count16f(a, b, c, d, u1);
+    const uint32_t y = g == 0u ? 0u : g - 1u;
+    const float v_lo = S.sky_marginal[y], v_hi = S.sky_marginal[y + 1];      // sky 4
+    load16f(t + S.cdf_off_c[2] + (size_t)y * S.cdf_stride_c[2], a, b, c, d);
+    const float dv = (u1 - v_lo) / (v_hi - v_lo + 1e-10f);
+    SkyUV r;
+    r.v = ((float)y + dv) / (float)H;
+    const float* row_cdf = S.sky_conditional + (size_t)y * (W + 1);
+    uint32_t h = count16f(a, b, c, d, u2);
+    load16f(t + S.cdf_off_c[1] + (size_t)y * S.cdf_stride_c[1] + 16u * h, a, b, c, d);     // sky 5
+    h = 16u * h + count16f(a, b, c, d, u2);
+    load16f(t + S.cdf_off_c[0] + (size_t)y * S.cdf_stride_c[0] + 16u * h, a, b, c, d);     // sky 6
+    h = 16u * h + count16f(a, b, c, d, u2);
+    const uint32_t x = h == 0u ? 0u : h - 1u;
+    const float u_lo = row_cdf[x], u_hi = row_cdf[x + 1];                     // sky 7
+    const float du = (u2 - u_lo) / (u_hi - u_lo + 1e-10f);
+    r.u = ((float)x + du) / (float)W;
+    return r;
+}
+PT_DEV SkySample sky_sample_at(const SceneDev& S, SkyUV uv, ShadeCnt& sc) {
+    SkySample r;
     // uv_to_direction (sky/texture.rs:120-125)
-    const float phi = (u - 0.5f) * 2.0f * PT_PI;
-    const float theta = (0.5f - v) * PT_PI;
+    const float phi = (uv.u - 0.5f) * 2.0f * PT_PI;
+    const float theta = (0.5f - uv.v) * PT_PI;
     float sph, cph, sth, cth;
     d_sincosf(phi, &sph, &cph);
     d_sincosf(theta, &sth, &cth);
     r.direction = sky_unrotate(S, v3(cth * sph, sth, cth * cph));
-    r.radiance = texture_sample(S.sky_tex, S.texels, u, v, sc.sky_texel);
+    r.radiance = texture_sample(S.sky_tex, S.texels, uv.u, uv.v, sc.sky_texel);
     r.pdf = sky_pdf(S, r.direction, sc);
     return r;
+}
+PT_DEV SkySample sky_sample_uniform(const SceneDev& S, float u1, float u2, ShadeCnt& sc) {
+    SkySample r;
+    const float phi = u1 * 2.0f * PT_PI;
+    const float cos_theta = 1.0f - 2.0f * u2;
+    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float sp, cp;
+    d_sincosf(phi, &sp, &cp);
+    r.direction = v3(sin_theta * cp, cos_theta, sin_theta * sp);
+    r.radiance = sky_sample(S, r.direction, sc);
+    r.pdf = 1.0f / (4.0f * PT_PI);
+    return r;
+}
+template <bool FAST>
+PT_DEV SkySample sky_sample_direction(const SceneDev& S, float u1, float u2, ShadeCnt& sc) {
+    if (S.sky_total_weight <= 0.0f) return sky_sample_uniform(S, u1, u2, sc);
+    return sky_sample_at(S, sky_search_uv<FAST>(S, u1, u2, sc), sc);
 }
 
 // -------------------------------------------------------------- brdf.rs -------
@@ -314,11 +379,10 @@ PT_DEV ShadeTri build_shade_tri(const SceneDev& S, const MeshRec& m, uint32_t tr
     return r;
 }
 
-PT_DEV HitData compute_hit_data(const SceneDev& S, uint32_t inst, uint32_t tri_idx, float t, float u, float v) {
-    const InstShade& is = S.inst_shade[inst];
-    const float4* q = reinterpret_cast<const float4*>(&S.shade_tris[(size_t)is.shade_base + tri_idx]);
-    const float4 qa = q[0], qb = q[1], qc = q[2], qd = q[3], qe = q[4];
-    const uint32_t mat_flags = is.mat_flags;
+// the arithmetic half: InstShade as three float4 (n[0..8], mesh id, shade_base, mat_flags) and the ShadeTri already in registers
+PT_DEV HitData hit_data_from(const float4 i0, const float4 i1, const float4 i2, const float4 qa, const float4 qb, const float4 qc,
+                             const float4 qd, const float4 qe, float t, float u, float v) {
+    const uint32_t mat_flags = __float_as_uint(i2.w);
     const float w = 1.0f - u - v;
     const V3 face_normal = v3(qa.x, qa.y, qa.z);
     V3 normal;
@@ -343,7 +407,7 @@ PT_DEV HitData compute_hit_data(const SceneDev& S, uint32_t inst, uint32_t tri_i
     h.t = t;
     h.material_id = mat_flags & SHADE_MATERIAL_MASK;
     // normal_matrix.transform_vector3(n).normalize()
-    const float* nm = is.n;
+    const float nm[9] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x};
     h.normal = normalize(v3((nm[0] * normal.x + nm[3] * normal.y) + nm[6] * normal.z,
                             (nm[1] * normal.x + nm[4] * normal.y) + nm[7] * normal.z,
                             (nm[2] * normal.x + nm[5] * normal.y) + nm[8] * normal.z));
@@ -351,6 +415,14 @@ PT_DEV HitData compute_hit_data(const SceneDev& S, uint32_t inst, uint32_t tri_i
                                 (nm[1] * geo_normal.x + nm[4] * geo_normal.y) + nm[7] * geo_normal.z,
                                 (nm[2] * geo_normal.x + nm[5] * geo_normal.y) + nm[8] * geo_normal.z));
     return h;
+}
+static_assert(sizeof(InstShade) == 48, "InstShade is read as three float4");
+PT_DEV HitData compute_hit_data(const SceneDev& S, uint32_t inst, uint32_t tri_idx, float t, float u, float v) {
+    const float4* isp = reinterpret_cast<const float4*>(&S.inst_shade[inst]);
+    const float4 i0 = isp[0], i1 = isp[1], i2 = isp[2];
+    const float4* q = reinterpret_cast<const float4*>(&S.shade_tris[(size_t)__float_as_uint(i2.z) + tri_idx]);
+    const float4 qa = q[0], qb = q[1], qc = q[2], qd = q[3], qe = q[4];
+    return hit_data_from(i0, i1, i2, qa, qb, qc, qd, qe, t, u, v);
 }
 
 // -------------------------------------------------------- sample_material -----

@@ -29,8 +29,17 @@ PT_DEV float powi5(float x) { const float x2 = x * x; const float x4 = x2 * x2; 
 PT_DEV float powi2(float x) { return x * x; }
 PT_DEV float fractf(float x) { return x - truncf(x); }
 PT_DEV bool finitef(float x) { return fabsf(x) < PT_INF; }   // false for NaN and +-inf
-PT_DEV float rem_euclid1(float x) { const float r = fmodf(x, 1.0f); return (r < 0.0f) ? r + 1.0f : r; }
-PT_DEV int rem_euclid_i(int a, int b) { const int r = a % b; return r < 0 ? r + b : r; }
+// f32::rem_euclid(1.0) (texture.rs:73-74).  fmod(x, 1) is x - trunc(x) exactly (the fractional part of a float is a float)
+// with the sign of x also on a zero result; OCML's general fmodf — an exponent loop, ~45 instructions — computed the same
+// bits.  Non-finite x gives NaN either way.
+PT_DEV float rem_euclid1(float x) { const float r = __builtin_copysignf(x - truncf(x), x); return (r < 0.0f) ? r + 1.0f : r; }
+// i32::rem_euclid (texture.rs:82-85).  A bilinear tap index lies in [-b, 2b) for every finite uv, where one conditional
+// add or subtract is the residue; the integer division (~25 instructions a piece) is kept for whatever else arrives.
+PT_DEV int rem_euclid_i(int a, int b) {
+    int r = a < 0 ? a + b : (a >= b ? a - b : a);
+    if (b <= 0 || (unsigned)r >= (unsigned)b) { r = a % b; r = r < 0 ? r + b : r; }
+    return r;
+}
 
 struct V3 { float x, y, z; };
 PT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
