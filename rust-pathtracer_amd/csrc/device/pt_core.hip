@@ -446,7 +446,8 @@ PT_DEV bool walk_begin_step(const PtxMaterial& material, V3 wt, float w_scale, R
 constexpr int WALK_BLOCK = PT_WALK_BLOCK;
 // The body of k_sss_step over queue entries first, first + stride, ... < n, for a block of BLOCK threads: the kernel runs
 // it grid-wide, the tail kernel (k_tail) on a wave's own paths.  c_* = the counters of the four queues it pushes to.
-template <bool CNT, int BLOCK>
+// ONCE: as in shade_range (the caller's grid covers the range in one stride)
+template <bool CNT, int BLOCK, bool ONCE = false>
 PT_DEV void sss_range(const SceneDev& S, const PathArrays& P, const uint32_t* q_walk, const uint32_t n, const uint32_t first, const uint32_t stride,
                       uint32_t* q_walk_next, uint32_t* q_next, uint32_t* q_shadow, uint32_t* q_final,
                       uint32_t* c_shadow, uint32_t* c_next, uint32_t* c_final, uint32_t* c_walk, const uint32_t max_bounces, ShadeCnt& sc) {
@@ -643,6 +644,7 @@ PT_DEV void sss_range(const SceneDev& S, const PathArrays& P, const uint32_t* q_
             if (active && alive && !exited) q_walk_next[o_wk + wave_rank(m_walk)] = p;
             if (active && alive && exited) q_next[o_ex + wave_rank(m_exit)] = p;
             if (active && !alive) q_final[o_fi + wave_rank(m_fin)] = p;      // walk returned None, roulette, or out of bounces
+            if (ONCE) break;
             __syncthreads();
         }
     }
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(WALK_BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
                                                          uint32_t* q_shadow, uint32_t* q_final, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
                                                          DevCounters* dc) {
     ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
-    sss_range<CNT, WALK_BLOCK>(S, P, q_walk, ctr->n_walk, blockIdx.x * blockDim.x, gridDim.x * blockDim.x, q_walk_next, q_next, q_shadow, q_final,
+    sss_range<CNT, WALK_BLOCK, !CNT>(S, P, q_walk, ctr->n_walk, blockIdx.x * blockDim.x, gridDim.x * blockDim.x, q_walk_next, q_next, q_shadow, q_final,
                                &ctr->n_shadow, &ctr_next->n_active, &ctr->n_final, &ctr_next->n_walk, max_bounces, sc);
     if (CNT) {
         wave_add(&dc->v[C_HITDATA], sc.hitdata);
@@ -667,7 +669,9 @@ __global__ __launch_bounds__(WALK_BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 // The body of k_shade over queue entries first, first + stride, ... < n, for a block of BLOCK threads (see sss_range).
 // SPEC ("Sky search ahead"): the two CDF searches of sample_sky_light start ahead of the hit-data and
 // material gathers, on the numbers the sky sample will draw unless the material draws first (transmission, subsurface).
-template <bool CNT, int BLOCK, bool SPEC = false>
+// ONCE: the caller's grid covers the range in one stride (k_shade<false, ..>): no loop, so nothing is hoisted out of one
+// and kept in scalar registers across the whole body.
+template <bool CNT, int BLOCK, bool SPEC = false, bool ONCE = false>
 PT_DEV void shade_range(const SceneDev& S, const PathArrays& P, const uint32_t* q, const uint32_t n, const uint32_t first, const uint32_t stride,
                         uint32_t* q_next, uint32_t* q_shadow, uint32_t* q_final, uint32_t* q_walk,
                         uint32_t* c_shadow, uint32_t* c_next, uint32_t* c_final, uint32_t* c_walk, const uint32_t max_bounces, ShadeCnt& sc) {
@@ -968,6 +972,7 @@ PT_DEV void shade_range(const SceneDev& S, const PathArrays& P, const uint32_t* 
             if (active && alive && !walk) q_next[o_nx + wave_rank(m_next)] = p;
             if (active && !alive) q_final[o_fi + wave_rank(m_fin)] = p;
             if (active && walk) q_walk[o_wk + wave_rank(m_walk)] = p;
+            if (ONCE) break;
             __syncthreads();   // s_cnt / s_base are rewritten by the next iteration
         }
     }
@@ -977,7 +982,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) PT_SHADE_ATTR void k_shade(SceneDev S,
                                                        uint32_t* q_final, uint32_t* q_walk, IterCtr* ctr, IterCtr* ctr_next, uint32_t max_bounces,
                                                        DevCounters* dc) {
     ShadeCnt sc = {0, 0, 0, 0, 0, 0, 0};
-    shade_range<CNT, SHADE_BLOCK, SPEC>(S, P, q, ctr->n_active, blockIdx.x * blockDim.x, gridDim.x * blockDim.x, q_next, q_shadow, q_final, q_walk,
+    shade_range<CNT, SHADE_BLOCK, SPEC, !CNT>(S, P, q, ctr->n_active, blockIdx.x * blockDim.x, gridDim.x * blockDim.x, q_next, q_shadow, q_final, q_walk,
                                   &ctr->n_shadow, &ctr_next->n_active, &ctr->n_final, &ctr_next->n_walk, max_bounces, sc);
     if (CNT) {
         wave_add(&dc->v[C_HITDATA], sc.hitdata);
@@ -2007,7 +2012,8 @@ static int32_t run_paths(PtxContext* ctx, const uint32_t* wl_pixel, const uint32
             // one state transition for every path in a subsurface event: continuing walks join qwb, finished events qb
             // (and this iteration's shadow queue), dead paths q_final
             ScopedEvent ev(ctx, CLS_WALK);
-            const int wg = (int)std::min<uint64_t>(256 * 64, (n + WALK_BLOCK - 1) / WALK_BLOCK);
+            // (one block per 256 slots the queue could hold, like k_shade: the uncounted kernel has no grid-stride loop)
+            const int wg = (int)((n + WALK_BLOCK - 1) / WALK_BLOCK);
             if (ctx->counting) hipLaunchKernelGGL(k_sss_step<true>, dim3(std::min(wg, 256 * 8)), dim3(WALK_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qwa, qwb, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
             else hipLaunchKernelGGL(k_sss_step<false>, dim3(wg), dim3(WALK_BLOCK), 0, ctx->stream, ctx->S, ctx->P, qwa, qwb, qb, ctx->q_shadow, ctx->q_final, c, c + 1, max_bounces, ctx->d_counters);
         }
