@@ -16,7 +16,10 @@ DEVICE_DEPS = ["csrc/device/pt_core.hip", "csrc/device/pt_detmath.h", "csrc/devi
 # -ffp-contract=off everywhere: the reference is rustc output, which never
 # fuses a*b+c, and bit-exact hit records depend on it.
 HOST_FLAGS = ["-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wall", "-Wextra"]
-DEVICE_FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math",
+# -fno-slp-vectorize: left on, the SLP vectorizer packs neighbouring scalar f32 operations into v_pk_mul_f32 / v_pk_add_f32,
+# which issue no faster than the two scalar instructions on gfx950 and need v_mov's to pair their operands: k_extend
+# 80 -> 74 VGPRs, 284 -> 197 moves, frame 550 -> 540 ms ("What the compiler was doing").
+DEVICE_FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
                 "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

@@ -649,14 +649,17 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
         }
         if (CNT) tv.lcp = &lc;
         if (tv.act == ACT_POP) tv.pop(S, st, lc);
-        if (FAST && tv.act == ACT_DONE && tv.amb_w && !tv.slow) {
-            // the result could depend on the walk order: the lane starts its ray over, in reference order (whatever the
-            // first attempt wrote through the sink is overwritten)
-            V3 o, d;
-            float tmax;
-            src.fetch(my, &o, &d, &tmax);
-            tv.begin(S, o, d, tmax, true);
-            n_again++;
+        if (FAST) {
+            const bool redo = tv.act == ACT_DONE && tv.amb_w && !tv.slow;
+            if (again_count) n_again += (uint32_t)__popcll(__ballot(redo));      // statistics: a wave-uniform count (a scalar register, not one per lane)
+            if (redo) {
+                // the result could depend on the walk order: the lane starts its ray over, in reference order (whatever the
+                // first attempt wrote through the sink is overwritten)
+                V3 o, d;
+                float tmax;
+                src.fetch(my, &o, &d, &tmax);
+                tv.begin(S, o, d, tmax, true);
+            }
         }
         if (tv.act == ACT_DONE) { sink.done(my, tv.found); tv.act = ACT_IDLE; }
 
@@ -693,25 +696,24 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
         const uint32_t nch = (tv.pw >> NODE_NCHILD_SHIFT) & NODE_NCHILD_MASK;      // children - 1 (node lanes)
         const bool wave_exact = __ballot(f_node && tv.exact) != 0ull;
         const bool wave_wide = __ballot(f_node && nch >= 3u) != 0ull;
-        float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
         if (f_tri || f_node) {
             // node lanes fetch the first three children of the unit they visit first (the second unit of a record that
-            // has one: its children are pushed first)
+            // has one: its children are pushed first).  The records live in this block only: declared outside it they
+            // cost the loop ~45 moves per iteration (zeros for the lanes that load nothing, copies where the paths merge).
             const float4* p = f_node ? reinterpret_cast<const float4*>(&S.nodes[(tv.pw & NODE_INDEX_MASK) + (nch >= 4u ? 1u : 0u)])
                                      : reinterpret_cast<const float4*>(&S.tris[tv.pw]);
-            r0 = p[0]; r1 = p[1]; r2 = p[2];
+            const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+            float4 r3, r4, r5;      // node lanes only
             if (f_node) { r3 = p[3]; r4 = p[4]; r5 = p[5]; }
-        }
-        if (f_tri) tv.do_tri(S, st, lc, r0, r1, r2);
-        if (f_node) {
-            if (wave_exact) tv.template do_node<true, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
-            else if (wave_wide) tv.template do_node<false, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
-            else tv.template do_node<false, false>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
+            if (f_tri) tv.do_tri(S, st, lc, r0, r1, r2);
+            if (f_node) {
+                if (wave_exact) tv.template do_node<true, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
+                else if (wave_wide) tv.template do_node<false, true>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
+                else tv.template do_node<false, false>(S, st, lc, err, r0, r1, r2, r3, r4, r5);
+            }
         }
     }
     if (FAST && again_count) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) n_again += (uint32_t)__shfl_xor((int)n_again, off);
         if (lane == 0u && n_again) atomicAdd(again_count, (unsigned long long)n_again);
     }
 }

@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "rust-pathtracer_amd")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC",
        "-c", f"-I{ROOT}/include", "csrc/device/pt_core.hip", "-o", "/tmp/pt_core_res.o", "-Rpass-analysis=kernel-resource-usage"]
 cmd += sys.argv[1:]
 r = subprocess.run(cmd, cwd=PKG, capture_output=True, text=True)
