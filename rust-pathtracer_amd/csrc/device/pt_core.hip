@@ -77,9 +77,17 @@ constexpr int PACKET_GRID = 256 * 4 * PT_PACKET_GRID_WAVES;   // the packet kern
 #ifndef PT_SHADOW_WAVES
 #define PT_SHADOW_WAVES PT_WAVES_PER_SIMD
 #endif
-constexpr int SHADOW_GRID = 256 * 4 * PT_SHADOW_WAVES;    // the any-hit kernel carries less state per lane
-constexpr int MAX_TRACE_GRID = 256 * 4 * (PT_SHADOW_WAVES > PT_WAVES_PER_SIMD ? PT_SHADOW_WAVES : PT_WAVES_PER_SIMD);
-constexpr int TRACE_GRID = 256 * 4 * PT_WAVES_PER_SIMD;   // persistent waves, PT_WAVES_PER_SIMD per SIMD: the VGPR and LDS budget
+// persistent waves per CU of the closest-hit / any-hit launches: what the VGPR budget (PT_WAVES_PER_SIMD per SIMD) and the
+// LDS stacks (6 KiB per wave: 26 waves in a CU's 160 KiB) let be resident together
+#ifndef PT_TRACE_GRID_PER_CU
+#define PT_TRACE_GRID_PER_CU (4 * PT_WAVES_PER_SIMD)
+#endif
+#ifndef PT_SHADOW_GRID_PER_CU
+#define PT_SHADOW_GRID_PER_CU (4 * PT_SHADOW_WAVES)
+#endif
+constexpr int SHADOW_GRID = 256 * PT_SHADOW_GRID_PER_CU;    // the any-hit kernel carries less state per lane
+constexpr int TRACE_GRID = 256 * PT_TRACE_GRID_PER_CU;
+constexpr int MAX_TRACE_GRID = SHADOW_GRID > TRACE_GRID ? SHADOW_GRID : TRACE_GRID;
 #ifndef PT_SHADE_GRID_PER_CU
 #define PT_SHADE_GRID_PER_CU (1 << 20)
 #endif

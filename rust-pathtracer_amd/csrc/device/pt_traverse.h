@@ -257,7 +257,9 @@ constexpr float FAST_UNDER = 1.0009765625f;  // 1 + m: the undershoot every hit 
 // to ~3m t(Y): ADVICE r2).
 constexpr float FAST_CULL_SLACKS = 4.0f;
 
-enum : uint32_t { ACT_IDLE = 0, ACT_NODE = 1, ACT_TRI = 2, ACT_ENTER = 3, ACT_EXIT = 4, ACT_POP = 5, ACT_DONE = 6 };
+// A lane that tests a leaf's triangles has act = ACT_TRI + the triangles left (1..128): the count rides in the action word
+// instead of a register of its own.
+enum : uint32_t { ACT_IDLE = 0, ACT_NODE = 1, ACT_ENTER = 3, ACT_EXIT = 4, ACT_POP = 5, ACT_DONE = 6, ACT_TRI = 16 };
 
 // Per-lane traversal state.  The world ray is not kept while a lane is inside an instance: it is re-read from the
 // queue entry when the instance is left; the closest hit is written through the sink when it is accepted.
@@ -284,7 +286,7 @@ struct Traverser {
     float m_u, m_v;
     uint32_t act;
     uint32_t pw;               // NODE: child word; TRI: next TriRec; ENTER: TLAS leaf word; EXIT: marker word
-    uint32_t tri_cnt;          // TRI: triangles left in the leaf
+    PT_DEV bool is_tri() const { return act > ACT_TRI; }
     bool in_mesh, found, exact;
     bool amb_w, amb_l;         // FAST: another hit within the band of the best one, at the world level / inside the current instance
     bool slow;                 // FAST kernels: this lane walks its ray in reference order (second attempt, or a ray outside the margins' range)
@@ -302,7 +304,6 @@ struct Traverser {
         sp = 0; tri_base = 0;
         m_tri = PTX_MISS; m_u = 0.0f; m_v = 0.0f;
         in_mesh = false; found = false;
-        tri_cnt = 0;
         pw = faithful() ? S.tlas_root_word : S.tlas_root_word_ray;
         // Bvh8::traverse_*: empty => None/false; the root is popped with dist 0.0: culled only if closest_t <= 0
         // (accel/bvh.rs:322-329)
@@ -331,10 +332,9 @@ struct Traverser {
             if (in_mesh) {
                 if (e.y == NEG_INF_BITS) act = ACT_EXIT;       // the marker: mesh level drained
                 else if (e.x & LEAF_FLAG) {
-                    act = ACT_TRI;
+                    act = ACT_TRI + ((e.x >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
                     if (CNT) leaf_dist = __uint_as_float(e.y);
                     pw = tri_base + (e.x & PRIM_START_MASK);
-                    tri_cnt = ((e.x >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
                 } else act = ACT_NODE;
             } else act = (e.x & LEAF_FLAG) ? ACT_ENTER : ACT_NODE;
             return;
@@ -453,8 +453,8 @@ struct Traverser {
     PT_DEV void do_tri(const SceneDev& S, const StackRef& st, LaneCnt& lc, const float4 ta, const float4 tb, const float4 tc) {
         const float tmin = RAY_EPSILON;
         if (CNT) { lc.prim_reads++; lc.tri_tests++; }
-        pw += 1u; tri_cnt -= 1u;
-        if (tri_cnt == 0u) act = ACT_POP;
+        pw += 1u; act -= 1u;
+        if (act == ACT_TRI) act = ACT_POP;
         // intersect_triangle with its early returns turned into one predicate: the same operations in the same
         // order, so a lane that reaches the end has the reference's t, u, v bit for bit; a lane the reference
         // would have returned early from computes values nobody reads
@@ -604,7 +604,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
     tv.act = ACT_IDLE;
     tv.exact = false; tv.in_mesh = false; tv.found = false; tv.amb_w = false; tv.amb_l = false; tv.slow = false;
     uint32_t n_again = 0;
-    tv.sp = 0; tv.pw = 0; tv.tri_cnt = 0; tv.tri_base = 0; tv.m_tri = PTX_MISS; tv.m_u = 0.0f; tv.m_v = 0.0f;
+    tv.sp = 0; tv.pw = 0; tv.tri_base = 0; tv.m_tri = PTX_MISS; tv.m_u = 0.0f; tv.m_v = 0.0f;
     tv.ct = 0.0f; tv.o = v3(0.0f, 0.0f, 0.0f); tv.d = tv.o; tv.inv = tv.o;
     tv.leaf_dist = 0.0f; tv.lcp = nullptr;
     uint32_t my = 0;
@@ -665,7 +665,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
 
         // vote: the action most lanes are waiting for runs, and so does any other with RUN_THRESHOLD lanes waiting
         const uint32_t cn = (uint32_t)__popcll(__ballot(tv.act == ACT_NODE));
-        const uint32_t ctn = (uint32_t)__popcll(__ballot(tv.act == ACT_TRI));
+        const uint32_t ctn = (uint32_t)__popcll(__ballot(tv.is_tri()));
         const uint32_t ce = (uint32_t)__popcll(__ballot(tv.act == ACT_ENTER));
         const uint32_t cx = (uint32_t)__popcll(__ballot(tv.act == ACT_EXIT));
         const uint32_t a = cn > ctn ? cn : ctn, b = ce > cx ? ce : cx;
@@ -689,7 +689,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
         }
         // Triangle and node lanes fetch their records together and wait once: the two sections used to pay one
         // memory round trip each, and a wave spends more time waiting on these loads than issuing.
-        const bool f_tri = (ctn == mx || ctn >= (ANY ? TH_ANY : TH_TRI)) && tv.act == ACT_TRI;
+        const bool f_tri = (ctn == mx || ctn >= (ANY ? TH_ANY : TH_TRI)) && tv.is_tri();
         const bool f_node = (cn == mx || cn >= (ANY ? TH_ANY : TH_NODE)) && tv.act == ACT_NODE;
         // wave-uniform choice of the node-visit variant: x86 NaN rule only if some lane can produce NaNs,
         // fourth child only if some lane's record has one
