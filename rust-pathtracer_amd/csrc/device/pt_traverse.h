@@ -73,10 +73,10 @@ namespace ptd {
 #define PT_LDS_STACK 12
 #endif
 #ifndef PT_REFILL_MIN_IDLE
-#define PT_REFILL_MIN_IDLE 13
+#define PT_REFILL_MIN_IDLE 15
 #endif
 #ifndef PT_REFILL_MIN_IDLE_ANY
-#define PT_REFILL_MIN_IDLE_ANY 40
+#define PT_REFILL_MIN_IDLE_ANY 48
 #endif
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 6
