@@ -1,16 +1,19 @@
 #!/bin/bash
-# On the GPU box: bench every library under rust-pathtracer_amd/lib/variants (tools/build_variant.sh) next to the shipped one,
-# one stream, three frames each:  bash tools/run_variants.sh [tag]  ->  gpurun_out/variants_<tag>.txt
-TAG=${1:-v}
-OUT=gpurun_out/variants_$TAG.txt
-: > $OUT
-for lib in "" rust-pathtracer_amd/lib/variants/*.so; do
-  PT_VARIANT_LIB=$lib PTX_OVERLAP_SHADOW=0 timeout -k 10 200 python bench.py --no-cpu-baseline --no-order-check --steps 3 > gpurun_out/variant_tmp.json 2> gpurun_out/variant_tmp.err || { echo "$lib FAILED" >> $OUT; continue; }
-  python - "$lib" >> $OUT <<'PY'
+# bash tools/run_variants.sh base v1 v2 ... : frame (one stream) per kernel class for libraries built by tools/build_variant.sh
+# CFGS="C3 C2" selects the configurations -> gpurun_out/variants.log
+mkdir -p gpurun_out; : > gpurun_out/variants.log
+for v in "$@"; do
+  if [ $v = base ]; then unset PT_VARIANT_LIB; else export PT_VARIANT_LIB=rust-pathtracer_amd/lib/variants/$v.so; fi
+  for c in ${CFGS:-C3}; do
+  PTX_OVERLAP_SHADOW=0 timeout -k 10 200 python3 tools/frame_breakdown.py $c uniform > /tmp/rv.log 2>&1 || { tail -5 /tmp/rv.log; exit 1; }
+  PTX_OVERLAP_SHADOW=1 timeout -k 10 200 python3 tools/frame_breakdown.py $c uniform > /tmp/rv2.log 2>&1 || { tail -5 /tmp/rv2.log; exit 1; }
+  python3 - $v $c <<'PY' | tee -a gpurun_out/variants.log
 import json, sys
-d = json.load(open("gpurun_out/variant_tmp.json"))
-k = d["kernel_ms_per_frame"]
-print(f"{(sys.argv[1].split('/')[-1] or 'shipped'):16s} frame {d['ms_per_step']:8.2f}  packet {k['packet_ms']:6.2f} extend {k['extend_ms']:7.2f} shade {k['shade_ms']:6.2f} shadow {k['shadow_ms']:7.2f} tail {k['tail_ms']:5.2f}  {d['verify']['sum_sha256_16']}")
+for f, lab in (('/tmp/rv.log', 'one stream'), ('/tmp/rv2.log', 'two streams')):
+    for l in open(f):
+        if '"part"' in l:
+            d = json.loads(l); t = d['timings']
+            print(sys.argv[1], d['config'][:14], lab, 'wall', d['wall_s'], {k: t[k] for k in ('packet_ms', 'extend_ms', 'shade_ms', 'shadow_ms', 'tail_ms')})
 PY
+  done
 done
-cat $OUT
