@@ -261,8 +261,7 @@ constexpr float FAST_CULL_SLACKS = 4.0f;
 // instead of a register of its own.
 enum : uint32_t { ACT_IDLE = 0, ACT_NODE = 1, ACT_ENTER = 3, ACT_EXIT = 4, ACT_POP = 5, ACT_DONE = 6, ACT_TRI = 16 };
 
-// Per-lane traversal state.  The world ray is not kept while a lane is inside an instance: it is re-read from the
-// queue entry when the instance is left; the closest hit is written through the sink when it is accepted.
+// Per-lane traversal state.  The closest hit is written through the sink when it is accepted, not carried.
 // UNC (FAST kernels): the scene holds meshes that failed the shape certificate; the TLAS visit looks for their flags
 #ifndef PT_ANY_ORDER
 #define PT_ANY_ORDER 2
@@ -279,6 +278,11 @@ struct Traverser {
     // reference's order: their events are its events.
     static constexpr int ANY_ORDER = (ANY && !CNT) ? PT_ANY_ORDER : 0;
     V3 o, d, inv;              // ray of the level being traversed
+    // The world ray stays in registers while the lane is inside an instance (round 3: the build without the SLP
+    // vectorizer left room for it; re-reading it from the queue entry at every exit cost k_extend 4.7 ms per frame).  The
+    // instantiation for scenes with uncertified meshes has no room and re-reads it.
+    static constexpr bool KEEP_W = !UNC;
+    V3 w_o, w_d;
     float ct;                  // closest_t of that level (ANY: its ray.t_max)
     int sp;                    // stack pointer (one typed stack for the three levels)
     uint32_t tri_base;         // first TriRec of the mesh being traversed
@@ -298,6 +302,7 @@ struct Traverser {
     PT_DEV bool faithful() const { return CNT || exact; }
     PT_DEV void begin(const SceneDev& S, V3 origin, V3 direction, float tmax, bool again = false) {
         o = origin; d = direction;
+        if (KEEP_W) { w_o = origin; w_d = direction; }
         inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);          // Ray::new (ray.rs:13-21)
         exact = ray_needs_exact(o, inv);
         ct = tmax;
@@ -550,9 +555,8 @@ struct Traverser {
         const uint32_t cur_inst = pw & MARK_INST_MASK;
         const uint2 e1 = st_read(st, sp - 1), e0 = st_read(st, sp - 2);
         sp -= 2;
-        V3 wo, wd;
-        float unused_tmax;
-        src.fetch(my, &wo, &wd, &unused_tmax);
+        V3 wo = w_o, wd = w_d;
+        if (!KEEP_W) { float unused_tmax; src.fetch(my, &wo, &wd, &unused_tmax); }
         float ct_world = __uint_as_float(e1.y);
         if (!ANY && m_tri != PTX_MISS) {
             if (CNT) lc.inst_hits++;
@@ -606,6 +610,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
     uint32_t n_again = 0;
     tv.sp = 0; tv.pw = 0; tv.tri_base = 0; tv.m_tri = PTX_MISS; tv.m_u = 0.0f; tv.m_v = 0.0f;
     tv.ct = 0.0f; tv.o = v3(0.0f, 0.0f, 0.0f); tv.d = tv.o; tv.inv = tv.o;
+    tv.w_o = tv.o; tv.w_d = tv.o;
     tv.leaf_dist = 0.0f; tv.lcp = nullptr;
     uint32_t my = 0;
     // Idle lanes claim queue entries with one wave-aggregated atomic as soon as REFILL_MIN_IDLE of them have
@@ -818,7 +823,8 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
         V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);          // Ray::new (ray.rs:13-21)
         bool exact = ray_needs_exact(o, inv);
         bool found = false;
-        V3 w_inv = inv;                 // world level, parked while the packet is inside an instance
+        const V3 w_o = o, w_d = d;      // world level, parked while the packet is inside an instance
+        V3 w_inv = inv;
         float w_ct = ct;
         bool w_exact = exact;
         uint32_t m_tri = PTX_MISS;
@@ -839,9 +845,7 @@ PT_DEV void trace_packets(const SceneDev& S, const NodeRec* __restrict__ g_nodes
                 // ---- tail of Instance::hit (accel/mod.rs:128-137) for the lanes that entered
                 const bool was = ((entered >> lane) & 1ull) != 0ull;
                 if (was) {
-                    V3 wo, wd;
-                    float unused_tmax;
-                    src.fetch(key, &wo, &wd, &unused_tmax);
+                    const V3 wo = w_o, wd = w_d;
                     if (!ANY && m_tri != PTX_MISS) {
                         const float4* p = reinterpret_cast<const float4*>(&g_inst[cur_inst]);
                         const float4 ma = p[5], mb = p[6], mc = p[7];
