@@ -142,8 +142,13 @@ PT_DEV uint32_t strip_lane() {
     asm volatile("" : "+v"(t));
     return t;
 }
+// Nearly every access stays in the LDS part (0.7 % of the pops reach the strips), and a per-lane "LDS or strip" branch
+// costs five or six scalar instructions of exec-mask bookkeeping per access on a CU whose one scalar unit is the
+// fullest unit under these kernels.  So the question is asked once per wave: if no active lane is in the strips (one
+// compare, one scalar branch) the access is a plain ds_read / ds_write; only otherwise the per-lane branches run.
 PT_DEV void st_write(const StackRef& s, int i, uint32_t word, uint32_t dist_bits) {
     const uint2 v = make_uint2(word, dist_bits);
+    if (__ballot(i >= LDS_STACK) == 0ull) { s_stack[i * TRACE_BLOCK + (int)threadIdx.x] = v; return; }
     if (i < LDS_STACK) s_stack[i * TRACE_BLOCK + (int)threadIdx.x] = v;
     else s.ovf[(size_t)(i - LDS_STACK) * s.ovf_stride + strip_lane()] = v;
 }
@@ -152,6 +157,11 @@ PT_DEV uint2 st_read(const StackRef& s, int i) {
     // selected address (slower than ds_read, and it ties LDS traffic to vmcnt); the empty asm is a side effect that
     // cannot be speculated, which keeps the branches and with them the address spaces apart.
     uint2 v;
+    if (__ballot(i >= LDS_STACK) == 0ull) {
+        v = s_stack[i * TRACE_BLOCK + (int)threadIdx.x];
+        asm volatile("" : "+v"(v.x), "+v"(v.y));
+        return v;
+    }
     if (i < LDS_STACK) {
         v = s_stack[i * TRACE_BLOCK + (int)threadIdx.x];
         asm volatile("" : "+v"(v.x), "+v"(v.y));
@@ -164,6 +174,11 @@ PT_DEV uint2 st_read(const StackRef& s, int i) {
 // the distance half of an entry alone (do_tri's check of a hit against its leaf's entry distance)
 PT_DEV float st_read_dist(const StackRef& s, int i) {
     uint32_t v;
+    if (__ballot(i >= LDS_STACK) == 0ull) {
+        v = s_stack[i * TRACE_BLOCK + (int)threadIdx.x].y;
+        asm volatile("" : "+v"(v));
+        return __uint_as_float(v);
+    }
     if (i < LDS_STACK) {
         v = s_stack[i * TRACE_BLOCK + (int)threadIdx.x].y;
         asm volatile("" : "+v"(v));
@@ -291,33 +306,42 @@ struct Traverser {
     uint32_t act;
     uint32_t pw;               // NODE: child word; TRI: next TriRec; ENTER: TLAS leaf word; EXIT: marker word
     PT_DEV bool is_tri() const { return act > ACT_TRI; }
-    bool in_mesh, found, exact;
-    bool amb_w, amb_l;         // FAST: another hit within the band of the best one, at the world level / inside the current instance
-    bool slow;                 // FAST kernels: this lane walks its ray in reference order (second attempt, or a ray outside the margins' range)
-    PT_DEV bool fast() const { return FAST && !slow; }
+    // The lane's flags live in ONE register.  As separate bools the compiler keeps each as a 64-bit lane mask in scalar
+    // registers and merges it with three scalar instructions behind every divergent region that may change it — six
+    // flags, eight regions per iteration — and a CU has one scalar unit for its four SIMDs: it ran at 0.70 instructions
+    // per cycle under k_extend, fuller than the vector units (0.48).  In a vector register the merges are free (exec-masked
+    // writes); a test costs two vector instructions.
+    //   F_IN_MESH  inside an instance      F_FOUND  a world-level hit has been accepted      F_EXACT  NaN-slab ray at this level
+    //   F_AMB_W / F_AMB_L (FAST)  another hit within the band of the best one, at the world level / inside the current instance
+    //   F_SLOW (FAST kernels)  this lane walks its ray in reference order (second attempt, or a ray outside the margins' range)
+    enum : uint32_t { F_IN_MESH = 1u, F_FOUND = 2u, F_EXACT = 4u, F_AMB_W = 8u, F_AMB_L = 16u, F_SLOW = 32u };
+    uint32_t fl;
+    PT_DEV bool get(uint32_t b) const { return (fl & b) != 0u; }
+    PT_DEV void put(uint32_t b, bool v) { fl = v ? (fl | b) : (fl & ~b); }
+    PT_DEV bool fast() const { return FAST && !get(F_SLOW); }
     float leaf_dist;           // counted kernels: entry distance of the leaf whose triangles are being tested
     LaneCnt* lcp;              // counted kernels: the lane's counters (visit_child has no other way to them)
 
     // which tree the current level is walked in: the faithful one for NaN-slab rays and for the counted kernels
-    PT_DEV bool faithful() const { return CNT || exact; }
+    PT_DEV bool faithful() const { return CNT || get(F_EXACT); }
     PT_DEV void begin(const SceneDev& S, V3 origin, V3 direction, float tmax, bool again = false) {
         o = origin; d = direction;
         if (KEEP_W) { w_o = origin; w_d = direction; }
         inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);          // Ray::new (ray.rs:13-21)
-        exact = ray_needs_exact(o, inv);
+        put(F_EXACT, ray_needs_exact(o, inv));
         ct = tmax;
         sp = 0; tri_base = 0;
         m_tri = PTX_MISS; m_u = 0.0f; m_v = 0.0f;
-        in_mesh = false; found = false;
+        put(F_IN_MESH, false); put(F_FOUND, false);
         pw = faithful() ? S.tlas_root_word : S.tlas_root_word_ray;
         // Bvh8::traverse_*: empty => None/false; the root is popped with dist 0.0: culled only if closest_t <= 0
         // (accel/bvh.rs:322-329)
         act = (S.n_tlas_nodes == 0 || (!ANY && 0.0f >= ct)) ? ACT_DONE : ACT_NODE;
         if (FAST) {
-            amb_l = false; amb_w = false;
+            put(F_AMB_L, false); put(F_AMB_W, false);
             // outside what the margins are certified for (or a second attempt): reference order
             const float dd = dot(d, d);
-            slow = again || exact || !(dd >= 0.5f && dd <= 2.0f) || !(((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) <= S.fast_omax);
+            put(F_SLOW, again || get(F_EXACT) || !(dd >= 0.5f && dd <= 2.0f) || !(((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) <= S.fast_omax));
         }
     }
     // FAST: what an entry distance is compared with (pop-time cull, the box test's t_max)
@@ -334,7 +358,7 @@ struct Traverser {
             const uint2 e = st_read(st, sp);
             if (!ANY && __uint_as_float(e.y) >= cb) continue;      // cb == closest_t for a reference-order walk (accel/bvh.rs:327-329)
             pw = e.x;
-            if (in_mesh) {
+            if (get(F_IN_MESH)) {
                 if (e.y == NEG_INF_BITS) act = ACT_EXIT;       // the marker: mesh level drained
                 else if (e.x & LEAF_FLAG) {
                     act = ACT_TRI + ((e.x >> PRIM_COUNT_SHIFT) & PRIM_COUNT_MASK) + 1u;
@@ -413,7 +437,7 @@ struct Traverser {
         const float4* p = reinterpret_cast<const float4*>(&S.nodes[pw & NODE_INDEX_MASK]);
         // the device stack (all levels of one ray share it) holds STACK_CAP entries; the reference's fixed arrays hold
         // 64 per level and panic beyond (accel/bvh.rs:320,361,379,408)
-        if (sp + (int)nchild > STACK_CAP) { atomicOr(err, 1u); found = false; act = ACT_DONE; return; }
+        if (sp + (int)nchild > STACK_CAP) { atomicOr(err, 1u); put(F_FOUND, false); act = ACT_DONE; return; }
         act = ACT_POP;
         if (FAST && UNC && !ANY) {      // compiled in only for scenes that hold an uncertified mesh (k_extend<.., true, true>)
             // A nearest-first lane culls by distance what the reference's walk may still visit.  That is only sound for
@@ -421,9 +445,9 @@ struct Traverser {
             // uncertified instance AT ANY DISTANCE (the reference's closest_t at that point is unknown, so none is
             // assumed) starts over in reference order.  Mesh records carry no such flag; scenes without an uncertified
             // mesh run the instantiation without this block.
-            uint32_t fl = (__float_as_uint(r1.w) | __float_as_uint(r3.w) | __float_as_uint(r5.w)) & META_UNCERT;
-            if (WIDE) fl |= META_UNCERT & (nchild > 3u ? 0xFFFFFFFFu : 0u);      // records of 4..8 children (host trees): look at every child
-            if (fl != 0u && fast() && !in_mesh) {
+            uint32_t unc = (__float_as_uint(r1.w) | __float_as_uint(r3.w) | __float_as_uint(r5.w)) & META_UNCERT;
+            if (WIDE) unc |= META_UNCERT & (nchild > 3u ? 0xFFFFFFFFu : 0u);      // records of 4..8 children (host trees): look at every child
+            if (unc != 0u && fast() && !get(F_IN_MESH)) {
                 bool touch = false;
                 float te;
                 if (!WIDE) {      // <= 3 children, already in registers
@@ -436,7 +460,7 @@ struct Traverser {
                         if ((__float_as_uint(hi.w) & META_UNCERT) != 0u && box_test<true>(lo, hi, o, inv, RAY_EPSILON, PT_INF, &te)) touch = true;
                     }
                 }
-                if (touch) { amb_w = true; found = false; act = ACT_DONE; return; }
+                if (touch) { put(F_AMB_W, true); put(F_FOUND, false); act = ACT_DONE; return; }
             }
         }
         if (WIDE && nchild > 4u) {
@@ -480,7 +504,7 @@ struct Traverser {
                 // ... and what of it the absolute slack of the margins does not cover (the relative part they must)
                 const float ux = ((leaf_dist - t) - S.fast_slack) / t; lc.undershoot_x = ux > lc.undershoot_x ? ux : lc.undershoot_x;
             }
-            if (ANY) { found = true; act = ACT_DONE; return; }
+            if (ANY) { put(F_FOUND, true); act = ACT_DONE; return; }
             if (FAST) {
                 // The presumption the margins rest on, checked on every hit a nearest-first lane is about to accept: the
                 // hit does not lie in front of its leaf box's entry distance by more than (1 + m) and the slack.  The
@@ -490,12 +514,12 @@ struct Traverser {
                 if (fast() && t < ct) {
                     // (read here, inside the hit branch: hoisted above the arithmetic the read costs 9 ms per frame)
                     const float ld = st_read_dist(st, sp);
-                    if (ld > t * FAST_UNDER + S.fast_slack) { amb_w = true; found = false; act = ACT_DONE; return; }
+                    if (ld > t * FAST_UNDER + S.fast_slack) { put(F_AMB_W, true); put(F_FOUND, false); act = ACT_DONE; return; }
                 }
                 // a second hit within the band of the instance's best one: which of them the reference's walk returns depends on its order
                 const bool have = m_tri != PTX_MISS;
-                if (t < ct) amb_l = have && ct <= band_bound(S, t);
-                else if (have && t <= band_bound(S, ct)) amb_l = true;
+                if (t < ct) put(F_AMB_L, have && ct <= band_bound(S, t));
+                else if (have && t <= band_bound(S, ct)) put(F_AMB_L, true);
             }
             if (t < ct) { ct = t; m_tri = __float_as_uint(tc.y); m_u = u; m_v = v; }
         }
@@ -510,7 +534,7 @@ struct Traverser {
         const float4 ia = p[0], ib = p[1], ic = p[2], b0 = p[3], b1 = p[4];
         const uint32_t inst_idx = S.tlas_prims[start];
         // TLAS leaf: this primitive now, the rest after the instance has been left
-        if (sp + 4 > STACK_CAP) { atomicOr(err, 1u); found = false; act = ACT_DONE; return; }     // remainder + 3-entry marker
+        if (sp + 4 > STACK_CAP) { atomicOr(err, 1u); put(F_FOUND, false); act = ACT_DONE; return; }     // remainder + 3-entry marker
         if (count > 1u) st_write(st, sp++, LEAF_FLAG | ((count - 2u) << PRIM_COUNT_SHIFT) | (start + 1u), NEG_INF_BITS);
         if (CNT) { lc.prim_reads++; lc.inst_entries++; lc.node_visits++; lc.node_children++; }
         const V3 lo = xf_point(ia, ib, ic, o);
@@ -524,11 +548,11 @@ struct Traverser {
         else bhit = box_test<false>(b0, make_float4(b1.x, b1.y, 0.0f, 0.0f), lo, linv, tmin, PT_INF, &tb_enter);
         // an instance of a mesh that failed the shape certificate (pt_types.h): the reference's walk, operation for operation
         const bool uncert = (__float_as_uint(b1.z) & INST_UNCERT) != 0u;
-        if (fast() && (lexact || uncert)) { amb_w = true; found = false; act = ACT_DONE; return; }      // NaN slabs in the local frame / uncertified: start over in reference order
-        if (FAST) amb_l = false;
+        if (fast() && (lexact || uncert)) { put(F_AMB_W, true); put(F_FOUND, false); act = ACT_DONE; return; }      // NaN slabs in the local frame / uncertified: start over in reference order
+        if (FAST) put(F_AMB_L, false);
         // a nearest-first lane must SEE every local hit that could tie with the best one: its bound carries the scene-wide
         // slack (>= this ray's rounding bound) four times over instead of the per-ray term
-        const float bound = (ANY || exact || lexact || uncert || (CNT && S.fwd_on < 2u)) ? PT_INF
+        const float bound = (ANY || get(F_EXACT) || lexact || uncert || (CNT && S.fwd_on < 2u)) ? PT_INF
                             : fast() ? ct * 1.03125f + 4.0f * S.fast_slack : forwarded_bound(S, o, d, ct);
         if (!bhit || (!ANY && tb_enter >= bound)) { act = ACT_POP; return; }
         if (CNT) lc.prim_reads++;   // the Blas leaf's own primitive index
@@ -536,12 +560,12 @@ struct Traverser {
         // (TriangleMesh::hit: closest_t = local t_max = +inf; root popped with dist 0)
         st_write(st, sp++, __float_as_uint(inv.x), __float_as_uint(inv.y));
         st_write(st, sp++, __float_as_uint(inv.z), __float_as_uint(ct));
-        st_write(st, sp++, inst_idx | (exact ? MARK_EXACT : 0u), NEG_INF_BITS);
+        st_write(st, sp++, inst_idx | (get(F_EXACT) ? MARK_EXACT : 0u), NEG_INF_BITS);
         if (CNT) lc.stack_hw = (uint32_t)sp > lc.stack_hw ? (uint32_t)sp : lc.stack_hw;
-        in_mesh = true;
+        put(F_IN_MESH, true);
         ct = bound;
         o = lo; d = ld; inv = linv;
-        exact = lexact;
+        put(F_EXACT, lexact);
         tri_base = __float_as_uint(b1.w);
         m_tri = PTX_MISS;
         // root record of the mesh BVH (absolute), child count in the top bits: wide tree, or the faithful one
@@ -566,26 +590,26 @@ struct Traverser {
             const V3 world_hit_point = xf_point(ma, mb, mc, local_hit_point);
             const float t_world = dot(world_hit_point - wo, wd) / dot(wd, wd);
             if (FAST) {
-                // this instance's winner against the best so far; a winner that is itself in doubt (amb_l) stands for
+                // this instance's winner against the best so far; a winner that is itself in doubt (F_AMB_L) stands for
                 // hits down to one band below it
-                if (amb_l && t_world <= band_bound(S, band_bound(S, ct_world))) amb_w = true;
+                if (get(F_AMB_L) && t_world <= band_bound(S, band_bound(S, ct_world))) put(F_AMB_W, true);
                 // (the ray's own finite t_max stands for a hit as well: the reference skips an instance whose box is
                 // entered at or beyond it, accel/bvh.rs:327,345, where this walk would still enter and accept — ADVICE r2)
-                const bool rival = found || ct_world < PT_INF;
-                if (t_world < ct_world) { if (!amb_l) amb_w = rival && ct_world <= band_bound(S, t_world); }
-                else if (found && t_world <= band_bound(S, ct_world)) amb_w = true;
+                const bool rival = get(F_FOUND) || ct_world < PT_INF;
+                if (t_world < ct_world) { if (!get(F_AMB_L)) put(F_AMB_W, rival && ct_world <= band_bound(S, t_world)); }
+                else if (get(F_FOUND) && t_world <= band_bound(S, ct_world)) put(F_AMB_W, true);
             }
             if (t_world < ct_world) {                               // traverse_closest accept (accel/bvh.rs:353-357)
                 ct_world = t_world;
                 sink.hit(my, cur_inst, m_tri, t_world, m_u, m_v);
-                found = true;
+                put(F_FOUND, true);
             }
         }
         m_tri = PTX_MISS;
-        in_mesh = false;
+        put(F_IN_MESH, false);
         o = wo; d = wd;
         inv = v3(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e1.x));
-        exact = (pw & MARK_EXACT) != 0u;
+        put(F_EXACT, (pw & MARK_EXACT) != 0u);
         ct = ct_world;
         act = ACT_POP;
     }
@@ -604,9 +628,10 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
     // a short queue cannot feed every wave: the surplus ones leave without touching the cursors (6144 waves bumping
     // a few addresses made an empty launch cost 70 us)
     if (!LOCAL && (unsigned long long)blockIdx.x * 16ull >= (unsigned long long)n + 128ull) return;
-    Traverser<ANY, CNT, FAST, UNC> tv;
+    using TV = Traverser<ANY, CNT, FAST, UNC>;
+    TV tv;
     tv.act = ACT_IDLE;
-    tv.exact = false; tv.in_mesh = false; tv.found = false; tv.amb_w = false; tv.amb_l = false; tv.slow = false;
+    tv.fl = 0u;
     uint32_t n_again = 0;
     tv.sp = 0; tv.pw = 0; tv.tri_base = 0; tv.m_tri = PTX_MISS; tv.m_u = 0.0f; tv.m_v = 0.0f;
     tv.ct = 0.0f; tv.o = v3(0.0f, 0.0f, 0.0f); tv.d = tv.o; tv.inv = tv.o;
@@ -655,7 +680,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
         if (CNT) tv.lcp = &lc;
         if (tv.act == ACT_POP) tv.pop(S, st, lc);
         if (FAST) {
-            const bool redo = tv.act == ACT_DONE && tv.amb_w && !tv.slow;
+            const bool redo = tv.act == ACT_DONE && tv.get(TV::F_AMB_W) && !tv.get(TV::F_SLOW);
             if (again_count) n_again += (uint32_t)__popcll(__ballot(redo));      // statistics: a wave-uniform count (a scalar register, not one per lane)
             if (redo) {
                 // the result could depend on the walk order: the lane starts its ray over, in reference order (whatever the
@@ -666,7 +691,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
                 tv.begin(S, o, d, tmax, true);
             }
         }
-        if (tv.act == ACT_DONE) { sink.done(my, tv.found); tv.act = ACT_IDLE; }
+        if (tv.act == ACT_DONE) { sink.done(my, tv.get(TV::F_FOUND)); tv.act = ACT_IDLE; }
 
         // vote: the action most lanes are waiting for runs, and so does any other with RUN_THRESHOLD lanes waiting
         const uint32_t cn = (uint32_t)__popcll(__ballot(tv.act == ACT_NODE));
@@ -699,7 +724,7 @@ PT_DEV void trace_queue(const SceneDev& S, const StackRef& st, uint32_t* work, c
         // wave-uniform choice of the node-visit variant: x86 NaN rule only if some lane can produce NaNs,
         // fourth child only if some lane's record has one
         const uint32_t nch = (tv.pw >> NODE_NCHILD_SHIFT) & NODE_NCHILD_MASK;      // children - 1 (node lanes)
-        const bool wave_exact = __ballot(f_node && tv.exact) != 0ull;
+        const bool wave_exact = __ballot(f_node && tv.get(TV::F_EXACT)) != 0ull;
         const bool wave_wide = __ballot(f_node && nch >= 3u) != 0ull;
         if (f_tri || f_node) {
             // node lanes fetch the first three children of the unit they visit first (the second unit of a record that
