@@ -296,7 +296,10 @@ struct Traverser {
     // The world ray stays in registers while the lane is inside an instance (round 3: the build without the SLP
     // vectorizer left room for it; re-reading it from the queue entry at every exit cost k_extend 4.7 ms per frame).  The
     // instantiation for scenes with uncertified meshes has no room and re-reads it.
-    static constexpr bool KEEP_W = !UNC;
+#ifndef PT_KEEP_WORLD
+#define PT_KEEP_WORLD 1
+#endif
+    static constexpr bool KEEP_W = PT_KEEP_WORLD != 0 && !UNC;
     V3 w_o, w_d;
     float ct;                  // closest_t of that level (ANY: its ray.t_max)
     int sp;                    // stack pointer (one typed stack for the three levels)

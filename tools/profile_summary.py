@@ -135,7 +135,10 @@ def limiters(root, out_path, config, source, frames=1):
             e["issue_wait_share"] = round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)
         if "SQ_INSTS_SALU" in c and "SQ_INSTS_VALU" in c:
             e["salu_per_valu"] = round(c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"], 4)
-        cand = {n: e[n] for n in ("hbm_traffic_frac", "l2_bw_frac", "valu_issue_frac") if n in e}
+            # a CU has ONE scalar unit for its four SIMDs (MI355X_MICROARCH.md: "4 SIMD-32 vector units, 1 scalar unit"), one
+            # instruction per clock: 256 CUs at the measured clock
+            e["salu_issue_frac"] = round(c["SQ_INSTS_SALU"] / (256 * clock * t), 4)
+        cand = {n: e[n] for n in ("hbm_traffic_frac", "l2_bw_frac", "valu_issue_frac", "salu_issue_frac") if n in e}
         if cand:
             e["binding"] = max(cand, key=cand.get)      # the throughput limit closest to its ceiling
         out[k] = e
