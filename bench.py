@@ -338,12 +338,12 @@ def main():
                 # counter bytes over THIS run's launch time
                 roofline["measured_hbm_frac"] = round(k["hbm_bytes_per_launch"] / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 roofline["limiters"] = {n: k[n] for n in ("hbm_traffic_frac", "l2_bw_frac", "l2_hit_rate", "valu_issue_frac", "valu_issue_frac_at_peak_clock",
-                                                         "clock_GHz_measured", "lanes_active", "mem_wait_share", "issue_wait_share", "salu_per_valu", "binding") if n in k}
+                                                         "clock_GHz_measured", "lanes_active", "mem_wait_share", "issue_wait_share", "salu_per_valu", "salu_issue_frac", "binding") if n in k}
                 roofline["limiters"]["source"] = lim.get("source")
                 # what actually binds the kernel (the contract's `bound` stays "hbm": achieved / peak are bytes per second)
                 roofline["binding_limiter"] = {"name": k.get("binding"), "frac": k.get(k.get("binding", ""), None),
                                                "clock_GHz": k.get("clock_GHz_measured"),
-                                               "note": "VALU issue: wave64 VALU instructions x 2 clocks / (1024 SIMDs x the clock measured in the same profile, GRBM_GUI_ACTIVE / 8 / kernel time)"}
+                                               "note": "VALU issue: wave64 VALU instructions x 2 clocks / (1024 SIMDs x the clock measured in the same profile, GRBM_GUI_ACTIVE / 8 / kernel time); salu_issue_frac: scalar instructions / (256 CUs x that clock): a CU has one scalar unit for its four SIMDs"}
         except Exception as e:      # a malformed profile file must not fail the bench
             roofline["limiters_error"] = str(e)
 

@@ -331,6 +331,27 @@ int32_t ptx_order_after_frame_tail(PtxContext* ctx, PtxContext* other);
 int32_t ptx_fb_adaptive_pass(PtxContext* ctx, const PtxAdaptiveConfig* cfg,
                              uint32_t max_bounces, uint64_t* out_rendered);
 
+/* The two halves of `render_adaptive_pass` for a frame split over several GPUs
+ * when `max_samples_per_pass` truncates the noisy list (renderloop/parallel.rs:
+ * 96-107: sort all noisy pixels by error, keep the first max): the cut is global,
+ * so the ranks' lists have to meet.  ptx_fb_noisy_pairs is `get_noisy_pixels`
+ * (framebuffer.rs:181-214) over the pixels this context owns, as host arrays:
+ * out_keys[i] orders like the pixel's error (larger = noisier, +inf for a pixel
+ * below min_samples), out_pixels[i] = y * width + x.  *out_n is always the
+ * count; with buffers that are null or too small nothing else is written and
+ * PTX_ERR_INVALID returned.  The caller gathers every rank's pairs, sorts them
+ * by key descending and pixel ascending (the reference's stable sort over
+ * row-major pixels), keeps the first max and hands each rank its own pixels:
+ * ptx_fb_adaptive_pass_pixels traces one sample of each (host array, every
+ * index < width * height, no pixel twice; sample_index = the pixel's count,
+ * parallel.rs:109-114) and accumulates it.  `render.adaptive_pass_distributed`
+ * is that loop; INTEGRATION.md shows it. */
+int32_t ptx_fb_noisy_pairs(PtxContext* ctx, const PtxAdaptiveConfig* cfg,
+                           uint32_t* out_keys, uint32_t* out_pixels,
+                           uint64_t capacity, uint64_t* out_n);
+int32_t ptx_fb_adaptive_pass_pixels(PtxContext* ctx, const uint32_t* pixels, uint64_t n,
+                                    uint32_t max_bounces, uint64_t* out_rendered);
+
 /* The adaptive loop of the app (app.rs:195-236: `render_adaptive_pass` once per
  * frame until it renders nothing): up to `max_passes` passes, stopping after
  * the first that finds no noisy pixel.  Same sum / sum_sq / counts as calling

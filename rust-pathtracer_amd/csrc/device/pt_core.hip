@@ -1229,6 +1229,26 @@ __global__ void k_compact_noisy(const uint32_t* owned, const uint32_t* keys, uin
         queue_push(out, out_count, sel, sel ? owned[i] : 0u);
     }
 }
+// the same selection with the key beside the pixel (ptx_fb_noisy_pairs: the list several ranks sort together)
+__global__ void k_compact_noisy_pairs(const uint32_t* owned, const uint32_t* keys, uint32_t n, uint32_t* out_pixels, uint32_t* out_keys, uint32_t* out_count) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        const bool sel = i < n && keys[i] != 0u;
+        const unsigned long long m = __ballot(sel);
+        if (m == 0ull) continue;
+        uint32_t b = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if ((int)(threadIdx.x & 63u) == leader) b = atomicAdd(out_count, (uint32_t)__popcll(m));
+        b = (uint32_t)__shfl((int)b, leader);
+        if (sel) { const uint32_t at = b + wave_rank(m); out_pixels[at] = owned[i]; out_keys[at] = keys[i]; }
+    }
+}
+// ptx_fb_adaptive_pass_pixels: every pixel of a caller's list must lie inside the framebuffer
+__global__ void k_check_pixels(const uint32_t* pixels, uint32_t n, uint32_t n_pixels, uint32_t* bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && pixels[i] >= n_pixels) atomicOr(bad, 1u);
+}
 __global__ void k_iota(uint32_t* a, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
 __global__ void k_gather(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* dst) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[idx[i]]; }
 
@@ -2710,6 +2730,65 @@ int32_t ptx_fb_adaptive_pass(PtxContext* ctx, const PtxAdaptiveConfig* cfg, uint
     if (st != PTX_OK) return st;
     add_primary_count(ctx, n_work);
     *out_rendered = n_work;
+    return check_device_error(ctx);
+}
+
+int32_t ptx_fb_noisy_pairs(PtxContext* ctx, const PtxAdaptiveConfig* cfg, uint32_t* out_keys, uint32_t* out_pixels, uint64_t capacity,
+                           uint64_t* out_n) {
+    REQUIRE_FB();
+    if (!cfg || !out_n) return fail(ctx, PTX_ERR_INVALID, "null argument");
+    if (!ctx->fb_adaptive) return fail(ctx, PTX_ERR_INVALID, "framebuffer was not created adaptive");
+    *out_n = 0;
+    int32_t st = ensure_worklist(ctx, ctx->fb_w, ctx->fb_h);
+    if (st != PTX_OK) return st;
+    const uint32_t n = ctx->wl_n;
+    if (n == 0) return PTX_OK;
+    st = ensure_lists(ctx, n);
+    if (st != PTX_OK) return st;
+    uint32_t* keys = ctx->list_b; uint32_t* pix = ctx->list_c; uint32_t* ckeys = ctx->list_d;
+    uint32_t* d_count = reinterpret_cast<uint32_t*>(&ctx->ctrs[CTR_ADAPTIVE]);
+    HIPCHK(hipMemsetAsync(d_count, 0, sizeof(IterCtr), ctx->stream));
+    const int grid = (int)std::min<uint32_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(k_noise_keys, dim3(grid), dim3(256), 0, ctx->stream, ctx->wl_pixel, n, ctx->fb_sum, ctx->fb_sum_sq, ctx->fb_counts,
+                       cfg->min_samples, cfg->variance_threshold, keys, d_count);
+    hipLaunchKernelGGL(k_compact_noisy_pairs, dim3(grid), dim3(256), 0, ctx->stream, ctx->wl_pixel, keys, n, pix, ckeys, d_count + 1);
+    HIPCHK(hipMemcpyAsync(ctx->h_pinned + 2, d_count + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint32_t n_noisy = ctx->h_pinned[2];
+    *out_n = n_noisy;
+    if (n_noisy == 0) return PTX_OK;
+    if (!out_keys || !out_pixels || capacity < n_noisy) return fail(ctx, PTX_ERR_INVALID, "ptx_fb_noisy_pairs: buffers too small (*out_n holds the count)");
+    HIPCHK(hipMemcpyAsync(out_keys, ckeys, (size_t)n_noisy * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_pixels, pix, (size_t)n_noisy * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PTX_OK;
+}
+
+int32_t ptx_fb_adaptive_pass_pixels(PtxContext* ctx, const uint32_t* pixels, uint64_t n64, uint32_t max_bounces, uint64_t* out_rendered) {
+    REQUIRE_FB();
+    if (!out_rendered || (n64 && !pixels)) return fail(ctx, PTX_ERR_INVALID, "null argument");
+    if (!ctx->fb_adaptive) return fail(ctx, PTX_ERR_INVALID, "framebuffer was not created adaptive");
+    *out_rendered = 0;
+    if (n64 == 0) return PTX_OK;
+    if (n64 > (uint64_t)ctx->fb_w * ctx->fb_h) return fail(ctx, PTX_ERR_INVALID, "more pixels than the framebuffer holds (a pixel may appear once per pass)");
+    const uint32_t n = (uint32_t)n64;
+    int32_t st = ensure_lists(ctx, std::max<uint64_t>(n, (uint64_t)ctx->fb_w * ctx->fb_h));
+    if (st != PTX_OK) return st;
+    uint32_t* work = ctx->list_c;
+    uint32_t* d_bad = reinterpret_cast<uint32_t*>(&ctx->ctrs[CTR_ADAPTIVE]);
+    HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(IterCtr), ctx->stream));
+    HIPCHK(hipMemcpyAsync(work, pixels, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_check_pixels, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, work, n, ctx->fb_w * ctx->fb_h, d_bad);
+    HIPCHK(hipMemcpyAsync(ctx->h_pinned + 2, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pinned[2] != 0u) return fail(ctx, PTX_ERR_INVALID, "pixel index outside the framebuffer");
+    Target tg{};
+    tg.sum = ctx->fb_sum; tg.sum_sq = ctx->fb_sum_sq; tg.counts = ctx->fb_counts;
+    // sample_index = the pixel's own sample count (parallel.rs:109-114)
+    st = run_paths(ctx, work, nullptr, ctx->fb_counts, 0, n, ctx->fb_w, ctx->fb_h, max_bounces, tg, false);
+    if (st != PTX_OK) return st;
+    add_primary_count(ctx, n);
+    *out_rendered = n;
     return check_device_error(ctx);
 }
 
