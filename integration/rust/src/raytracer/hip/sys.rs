@@ -257,6 +257,10 @@ extern "C" {
     pub fn ptx_fb_render_passes_async(ctx: *mut PtxContext, first_sample: u32, count: u32, max_bounces: u32) -> i32;
     pub fn ptx_fb_adaptive_pass(ctx: *mut PtxContext, cfg: *const PtxAdaptiveConfig, max_bounces: u32, out_rendered: *mut u64) -> i32;
     pub fn ptx_fb_adaptive_passes(ctx: *mut PtxContext, cfg: *const PtxAdaptiveConfig, max_bounces: u32, max_passes: u32, out_passes: *mut u32, out_rendered: *mut u64) -> i32;
+    /// The two halves of `render_adaptive_pass` for a frame split over several GPUs when `max_samples_per_pass` truncates:
+    /// this rank's noisy pixels as (key, pixel) host arrays, and one adaptive sample for an explicit list of pixels.
+    pub fn ptx_fb_noisy_pairs(ctx: *mut PtxContext, cfg: *const PtxAdaptiveConfig, out_keys: *mut u32, out_pixels: *mut u32, capacity: u64, out_n: *mut u64) -> i32;
+    pub fn ptx_fb_adaptive_pass_pixels(ctx: *mut PtxContext, pixels: *const u32, n: u64, max_bounces: u32, out_rendered: *mut u64) -> i32;
     pub fn ptx_fb_stats(ctx: *mut PtxContext, out_min: *mut u32, out_max: *mut u32, out_total: *mut u64) -> i32;
     pub fn ptx_fb_read(ctx: *mut PtxContext, out_sum: *mut f32, out_sum_sq: *mut f32, out_counts: *mut u32) -> i32;
     pub fn ptx_fb_read_mean(ctx: *mut PtxContext, out_mean: *mut f32) -> i32;

@@ -25,6 +25,7 @@ EXPORTS = [
     "ptx_get_timings", "ptx_debug_math", "ptx_render_frame", "ptx_fb_tonemap_srgb8", "ptx_fb_adaptive_passes",
     "ptx_get_debug_stats", "ptx_trace_batch_noalloc", "ptx_fb_tiles_bytes", "ptx_fb_export_tiles_dev", "ptx_fb_import_tiles_dev",
     "ptx_order_after_stream", "ptx_order_stream_after", "ptx_fb_render_passes_async", "ptx_order_after_frame_tail",
+    "ptx_fb_noisy_pairs", "ptx_fb_adaptive_pass_pixels",
 ]
 
 
@@ -61,6 +62,8 @@ def lib():
     L.ptx_fb_render_passes_async.argtypes = [vp, u32, u32, u32]
     L.ptx_fb_adaptive_pass.argtypes = [vp, C.POINTER(abi.PtxAdaptiveConfig), u32, C.POINTER(u64)]
     L.ptx_fb_adaptive_passes.argtypes = [vp, C.POINTER(abi.PtxAdaptiveConfig), u32, u32, C.POINTER(u32), C.POINTER(u64)]
+    L.ptx_fb_noisy_pairs.argtypes = [vp, C.POINTER(abi.PtxAdaptiveConfig), vp, vp, u64, C.POINTER(u64)]
+    L.ptx_fb_adaptive_pass_pixels.argtypes = [vp, vp, u64, u32, C.POINTER(u64)]
     L.ptx_fb_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
     L.ptx_fb_read.argtypes = [vp, vp, vp, vp]
     L.ptx_fb_read_mean.argtypes = [vp, vp]
@@ -210,6 +213,27 @@ class HipRenderLoop:
         cfg = abi.PtxAdaptiveConfig(config.min_samples, config.variance_threshold, mx)
         n = C.c_uint64(0)
         self._check(self.L.ptx_fb_adaptive_pass(self._h, C.byref(cfg), renderer.max_bounces, C.byref(n)), "ptx_fb_adaptive_pass")
+        return int(n.value)
+
+    def noisy_pairs(self, framebuffer, config):
+        """`get_noisy_pixels` (framebuffer.rs:181-214) over the pixels this loop owns: (keys, pixels), two uint32 arrays.
+        A larger key is a larger error (+inf below `min_samples`); pixel = y * width + x."""
+        framebuffer._require(self)
+        cfg = abi.PtxAdaptiveConfig(config.min_samples, config.variance_threshold, framebuffer.width * framebuffer.height)
+        cap = framebuffer.width * framebuffer.height
+        keys, pixels = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32)
+        n = C.c_uint64(0)
+        self._check(self.L.ptx_fb_noisy_pairs(self._h, C.byref(cfg), _p(keys), _p(pixels), cap, C.byref(n)), "ptx_fb_noisy_pairs")
+        return keys[:n.value].copy(), pixels[:n.value].copy()
+
+    def adaptive_pass_pixels(self, scene, camera, renderer, framebuffer, pixels):
+        """One adaptive sample for each pixel of `pixels` (y * width + x, none twice), `sample_index` = the pixel's own
+        count (parallel.rs:109-114), accumulated into the framebuffer.  Returns the number of samples added."""
+        self._bind(scene, camera)
+        framebuffer._require(self)
+        pixels = np.ascontiguousarray(pixels, dtype=np.uint32)
+        n = C.c_uint64(0)
+        self._check(self.L.ptx_fb_adaptive_pass_pixels(self._h, _p(pixels), len(pixels), renderer.max_bounces, C.byref(n)), "ptx_fb_adaptive_pass_pixels")
         return int(n.value)
 
     def render_adaptive_passes(self, scene, camera, renderer, framebuffer, config, max_passes):
@@ -445,6 +469,70 @@ def render_frame_distributed(all_reduce_max, loop, fb, scene, camera, renderer, 
         passes, rendered = loop.render_adaptive_passes(scene, camera, renderer, fb, adaptive, max_spp - spp)
         passes = all_reduce_max(passes)
     return rendered, passes
+
+
+def select_truncated(keys, pixels, max_samples_per_pass):
+    """`render_adaptive_pass`'s cut (renderloop/parallel.rs:96-107) over the noisy pixels of ALL ranks: stable sort by
+    error descending — `get_noisy_pixels` lists pixels in row-major order, so ties keep ascending pixel order — then
+    `truncate(max)`.  `keys` / `pixels`: the concatenation of every rank's `noisy_pairs`.  Returns the surviving pixels
+    in sorted order."""
+    keys = np.asarray(keys, dtype=np.uint32)
+    pixels = np.asarray(pixels, dtype=np.uint32)
+    order = np.lexsort((pixels, -keys.astype(np.int64)))
+    return pixels[order[:max(0, int(max_samples_per_pass))]]
+
+
+def tile_owner(pixels, width, world):
+    """Rank that owns each pixel under `ptx_set_partition` (8x8 tiles, tile index % world)."""
+    pixels = np.asarray(pixels, dtype=np.int64)
+    tx_n = (width + TILE - 1) // TILE
+    return ((pixels // width // TILE) * tx_n + (pixels % width) // TILE) % world
+
+
+def adaptive_pass_distributed(all_gather, loop, fb, scene, camera, renderer, config, rank, world):
+    """One `render_adaptive_pass` (renderloop/parallel.rs:80-123) of a frame split over `world` GPUs, for configurations
+    whose `max_samples_per_pass` may truncate the noisy list — the one case in which the ranks' lists have to meet,
+    because the cut is taken over the error-sorted list of ALL noisy pixels.  Every rank lists its own noisy pixels
+    (`ptx_fb_noisy_pairs`), ONE all-gather makes the lists global (`all_gather(keys, pixels) -> (all_keys, all_pixels)`:
+    torch.distributed over RCCL or gloo, `gather_pairs_torch` below, or a stub in tests; at most 8 bytes per pixel of the
+    frame), every rank takes the same cut (`select_truncated`) and samples the survivors among its own tiles
+    (`ptx_fb_adaptive_pass_pixels`).  A pixel's sample depends only on its own count, so the ranks' framebuffers combine
+    (`TileExchange`) to the single-GPU pass bit for bit.  Returns (samples this rank added, samples of the whole pass).
+    Without truncation `render_frame_distributed` needs no exchange at all and traces 32+ passes together; use this only
+    when `max_samples_per_pass` can bite."""
+    mx = config.max_samples_per_pass
+    if mx is None:
+        mx = fb.width * fb.height
+    keys, pixels = loop.noisy_pairs(fb, config)
+    all_keys, all_pixels = all_gather(keys, pixels)
+    chosen = select_truncated(all_keys, all_pixels, mx)
+    mine = chosen[tile_owner(chosen, fb.width, world) == rank]
+    added = loop.adaptive_pass_pixels(scene, camera, renderer, fb, mine) if len(mine) else 0
+    return added, int(len(chosen))
+
+
+def gather_pairs_torch(dist, device=None):
+    """`all_gather` for `adaptive_pass_distributed` over torch.distributed: sizes first, then one padded all-gather of
+    (key, pixel) pairs.  `device` = the tensors' device ("cuda" for the nccl backend = RCCL, None / "cpu" for gloo)."""
+    import torch
+
+    def gather(keys, pixels):
+        world = dist.get_world_size()
+        n = torch.tensor([len(keys)], dtype=torch.int64, device=device)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(sizes, n)
+        sizes = [int(s.item()) for s in sizes]
+        cap = max(1, max(sizes))
+        mine = torch.zeros((cap, 2), dtype=torch.int64, device=device)
+        if len(keys):
+            mine[:len(keys), 0] = torch.from_numpy(keys.astype(np.int64)).to(mine.device)
+            mine[:len(keys), 1] = torch.from_numpy(pixels.astype(np.int64)).to(mine.device)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        k = np.concatenate([p[:s, 0].cpu().numpy() for p, s in zip(parts, sizes)]).astype(np.uint32)
+        x = np.concatenate([p[:s, 1].cpu().numpy() for p, s in zip(parts, sizes)]).astype(np.uint32)
+        return k, x
+    return gather
 
 
 class DeviceFramebuffer:

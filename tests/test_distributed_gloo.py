@@ -96,3 +96,57 @@ def test_two_rank_gloo_frame_equals_single_rank(pkg, oracle_det, tmp_path):
     assert np.array_equal(got["c"].reshape(h, w), c.astype(np.int32))
     assert np.array_equal(got["s"].reshape(h, w, 3).view(np.uint32), s.view(np.uint32))
     assert np.array_equal(got["q"].reshape(h, w, 3).view(np.uint32), q.view(np.uint32))
+
+
+def test_select_truncated_is_the_reference_cut(pkg):
+    """`select_truncated` against the reference's own words (renderloop/parallel.rs:96-107): the noisy pixels in
+    row-major order, a STABLE sort by error descending, truncate(max) — with many tied errors (the +inf of pixels below
+    min_samples), whatever order the ranks' lists arrive in."""
+    rng = np.random.default_rng(5)
+    w, h = 37, 23
+    err = rng.choice(np.array([0.0, 0.01, 0.02, 0.5, np.inf], dtype=np.float32), size=w * h)
+    noisy = np.nonzero(err > 0.005)[0]
+    # the reference: Vec of (pixel, err) in row-major order, sort_by(|a, b| b.err.partial_cmp(a.err)) (stable), truncate
+    ref = sorted(noisy.tolist(), key=lambda p: -float(err[p]) if np.isfinite(err[p]) else -1e30)
+    keys = err.view(np.uint32) + 1                         # k_noise_keys: f32 order of a non-negative error, +1
+    for world in (1, 2, 3, 8):
+        owner = pkg.render.tile_owner(noisy, w, world)
+        chunks = [noisy[owner == r] for r in range(world)]
+        for c in chunks:
+            rng.shuffle(c)                                  # a rank's list is in no particular order
+        allp = np.concatenate(chunks[::-1]).astype(np.uint32)
+        for mx in (0, 1, 17, len(noisy) // 2, len(noisy), len(noisy) + 5):
+            got = pkg.render.select_truncated(keys[allp], allp, mx)
+            assert got.tolist() == ref[:mx]
+    # tile_owner agrees with the partition the device uses
+    for world in (2, 3):
+        for r in range(world):
+            mine = pkg.render.partition_pixels(w, h, r, world)
+            assert (pkg.render.tile_owner(mine, w, world) == r).all()
+
+
+def _gather_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    n = [5, 0, 9][rank]                                       # ragged, one rank with nothing noisy
+    keys = (np.arange(n, dtype=np.uint32) * 7 + rank + 0x7F800001 * (rank == 2)).astype(np.uint32)    # keys beyond 2^31 survive the trip
+    pixels = np.arange(n, dtype=np.uint32) + 100 * rank
+    k, x = pkg.render.gather_pairs_torch(dist)(keys, pixels)
+    np.savez(os.path.join(out_dir, f"g{rank}.npz"), k=k, x=x)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_pairs_over_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want_k = np.concatenate([(np.arange(n, dtype=np.uint32) * 7 + r + 0x7F800001 * (r == 2)).astype(np.uint32) for r, n in enumerate([5, 0, 9])])
+    want_x = np.concatenate([np.arange(n, dtype=np.uint32) + 100 * r for r, n in enumerate([5, 0, 9])])
+    for r in range(world):
+        got = np.load(tmp_path / f"g{r}.npz")
+        assert got["k"].dtype == np.uint32 and np.array_equal(got["k"], want_k) and np.array_equal(got["x"], want_x)

@@ -338,6 +338,70 @@ def test_device_tonemap_srgb8(pkg, loop, oracle_det, scenes, tmp_path):
         pkg.PngExporter("filmic")
 
 
+def test_truncating_adaptive_pass_split_over_ranks(pkg, loop, scenes, oracle_det):
+    """`max_samples_per_pass` below the noisy count (renderloop/parallel.rs:96-107) on several GPUs: the cut is taken over
+    the error-sorted list of ALL noisy pixels, so the ranks' lists meet in one all-gather (`adaptive_pass_distributed`:
+    `ptx_fb_noisy_pairs` -> gather -> `select_truncated` -> `ptx_fb_adaptive_pass_pixels`).  Three virtual ranks = three
+    contexts on this GPU, one thread each, a barrier standing in for the collective.  After every pass the combined
+    buffers must equal the single-GPU `ptx_fb_adaptive_pass` AND the oracle's `render_adaptive_pass`, bit for bit."""
+    import threading
+    from oracle_py import OracleFramebuffer
+    sc = scenes("cornell", 1, 1.0)
+    w, h, spp, world, n_pass = 72, 40, 5, 3, 4
+    cam = sc.default_camera(w / h)
+    r8 = pkg.PathTracer(8)
+    cfg = pkg.AdaptiveSamplingConfig(min_samples=4, variance_threshold=0.03, max_samples_per_pass=700)
+    # single GPU and oracle, pass by pass
+    single = pkg.DeviceFramebuffer(loop, w, h, adaptive=True)
+    single.render_passes(sc, cam, r8, 0, spp)
+    ofb = OracleFramebuffer(oracle_det.scene(sc), w, h, True)
+    ofb.render_passes(cam, 0, spp, 8)
+    want, rendered = [], []
+    for _ in range(n_pass):
+        rendered.append(loop.render_adaptive_pass(sc, cam, r8, single, cfg))
+        ofb.adaptive_pass(cam, cfg.min_samples, cfg.variance_threshold, cfg.max_samples_per_pass, 8)
+        got, ora = single.read(), ofb.read()
+        assert np.array_equal(bits(got[0]), bits(ora[0])) and np.array_equal(bits(got[1]), bits(ora[1])) and np.array_equal(got[2], ora[2])
+        want.append(got)
+    assert rendered[0] == 700 and len(loop.noisy_pairs(single, cfg)[0]) > 0          # the cut did bite
+    barrier, pairs, parts, errors = threading.Barrier(world), [None] * world, [[None] * n_pass for _ in range(world)], []
+    totals = [[0] * n_pass for _ in range(world)]
+
+    def rank_main(r):
+        try:
+            def all_gather(keys, pixels):
+                pairs[r] = (keys, pixels)
+                barrier.wait()
+                k = np.concatenate([p[0] for p in pairs]); x = np.concatenate([p[1] for p in pairs])
+                barrier.wait()
+                return k, x
+            lp = pkg.HipRenderLoop(0)
+            lp.set_partition(r, world)
+            fb = pkg.DeviceFramebuffer(lp, w, h, adaptive=True)
+            fb.render_passes(sc, cam, r8, 0, spp)
+            for k in range(n_pass):
+                _, totals[r][k] = pkg.render.adaptive_pass_distributed(all_gather, lp, fb, sc, cam, r8, cfg, r, world)
+                parts[r][k] = fb.read()
+            # a list with a pixel outside the framebuffer is refused, not traced
+            with pytest.raises(pkg.RenderCoreError):
+                lp.adaptive_pass_pixels(sc, cam, r8, fb, np.array([w * h], dtype=np.uint32))
+        except Exception as e:   # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    for k in range(n_pass):
+        assert all(totals[r][k] == rendered[k] for r in range(world))
+        total = [sum(parts[r][k][j] for r in range(world)) for j in range(3)]      # disjoint tiles + zeros
+        assert np.array_equal(total[2], want[k][2])
+        assert np.array_equal(bits(total[0]), bits(want[k][0])) and np.array_equal(bits(total[1]), bits(want[k][1]))
+
+
 def test_adaptive_frame_split_over_ranks_is_the_single_gpu_frame(pkg, loop, scenes):
     """BASELINE config 5 on several GPUs: every rank runs uniform + adaptive passes on its interleaved tiles on its own
     (the pass cap is the same everywhere; one all-reduce(MAX) of the pass count for the statistics); the combined
