@@ -95,9 +95,12 @@ constexpr int MAX_TRACE_GRID = SHADOW_GRID > TRACE_GRID ? SHADOW_GRID : TRACE_GR
 #define PT_SHADE_BLOCK 256
 #endif
 constexpr int SHADE_BLOCK = PT_SHADE_BLOCK;
-// k_shade is a chain of dependent gathers: it runs at the speed its resident waves allow.  168 VGPRs = 3 waves/SIMD
-// without spilling (pending contributions, shadow ray and radiance are stored where they are computed to get there;
-// 4 waves need 88 B of scratch per lane: +0.6 % on the large frames, slower on the small ones).
+// the uncounted k_shade / k_sss_step have no grid-stride loop: their grids must cover any queue in one stride
+static_assert((unsigned long long)256 * PT_SHADE_GRID_PER_CU * PT_SHADE_BLOCK >= (1ull << 32), "k_shade<false, ..> visits one entry per thread: its grid may not be capped");
+// k_shade is a chain of dependent gathers: it runs at the speed its resident waves allow.  The attribute only sets the
+// floor (3 waves/SIMD = 168 VGPRs, what the kernel needed while a grid-stride loop kept every kernel argument live across
+// its body); the uncounted kernels have no such loop any more and take 91-102 VGPRs: 4 waves/SIMD, no scratch (5 waves
+// were measured with the 36 B of scratch that costs: slower).  DESIGN.md 4, "What the compiler was doing".
 #ifndef PT_SHADE_ATTR
 #define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(3)))
 #endif
