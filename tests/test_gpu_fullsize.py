@@ -354,6 +354,29 @@ def test_side_stream_overlap_changes_nothing(pkg, oracle_det, full_scenes, monke
     assert np.array_equal(bits(frames[0][3]), bits(oracle_det.scene(sc).render_pass(cam, w, h, 2, bounces)))
 
 
+def test_sky_search_ahead_changes_nothing(pkg, oracle_det, full_scenes, monkeypatch):
+    """By default k_shade starts the sky-light sample's table searches ahead of the hit-data gathers, on the numbers the
+    sample will draw unless the material draws first (`k_shade<false, true>`, `gather_hit_and_sky`); vertices on glass or
+    subsurface materials, which do draw first, search again with their own numbers.  The frame must be the
+    `PTX_SKY_AHEAD=0` frame bit for bit — plain passes, adaptive passes, the subsurface walk queue — and equal the
+    oracle's.  `PTX_TAIL_CAP` keeps the paths in k_shade (k_tail's shading phase never searches ahead)."""
+    sc = full_scenes("bistro_like")           # flags 3: HDR sky + sun + glass and SSS materials
+    w, h, spp, bounces = 192, 108, 5, 16
+    cam = sc.default_camera(w / h)
+    frames = []
+    monkeypatch.setenv("PTX_TAIL_CAP", "3000")
+    for ahead in ("1", "0"):
+        monkeypatch.setenv("PTX_SKY_AHEAD", ahead)
+        lp = pkg.HipRenderLoop(0)
+        fb = pkg.DeviceFramebuffer(lp, w, h, adaptive=True)
+        fb.render_passes(sc, cam, pkg.PathTracer(bounces), 0, spp)
+        lp.render_adaptive_passes(sc, cam, pkg.PathTracer(bounces), fb, pkg.AdaptiveSamplingConfig(4, 0.0005), 2)
+        frames.append(fb.read() + (lp.render_pass(sc, cam, pkg.PathTracer(bounces), w, h, 3),))
+    for a, b in zip(frames[0], frames[1]):
+        assert np.array_equal(bits(a), bits(b))
+    assert np.array_equal(bits(frames[0][3]), bits(oracle_det.scene(sc).render_pass(cam, w, h, 3, bounces)))
+
+
 def test_tail_kernel_changes_nothing(pkg, oracle_det, full_scenes, monkeypatch):
     """By default the late iterations of a batch run as one k_tail launch (every wave carries its own paths through
     extend -> shade -> walk step -> shadow -> finalize until they end; run_paths).  The frame must be the
